@@ -1,0 +1,368 @@
+"""CPU oracle for UCDIR's diffusion-sampling hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional (state-dict driven) fp32 restatement of the
+reference algorithm.  It exists so that the HIP path can be checked on the GPU box,
+where /root/reference does not exist.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it; nothing under ``ucdir_amd/`` does.
+
+Pinning: ``oracle/gen_golden.py`` imports the real reference (in the build container
+only) and stores its outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks every function below against those fixtures, and
+``tests/test_oracle_vs_reference.py`` compares live when the reference is present.
+The reference itself has no tests or golden vectors, so those
+generated fixtures are the only pins.
+
+Each function cites the reference lines it restates (paths relative to the
+reference repo root).
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# schedule (model/diffusion.py:23-54, 101-148)
+# ----------------------------------------------------------------------------------------------
+def make_betas(schedule: str, n_timestep: int, linear_start: float, linear_end: float) -> np.ndarray:
+    """model/diffusion.py:23-54 (the variants the configs can name)."""
+    if schedule == "linear":
+        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+    if schedule == "quad":
+        return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    if schedule == "const":
+        return linear_end * np.ones(n_timestep, dtype=np.float64)
+    if schedule == "jsd":
+        return 1.0 / np.linspace(n_timestep, 1, n_timestep, dtype=np.float64)
+    if schedule in ("warmup10", "warmup50"):
+        frac = 0.1 if schedule == "warmup10" else 0.5
+        betas = linear_end * np.ones(n_timestep, dtype=np.float64)
+        n = int(n_timestep * frac)
+        betas[:n] = np.linspace(linear_start, linear_end, n, dtype=np.float64)
+        return betas
+    if schedule == "cosine":
+        s = 8e-3
+        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + s
+        al = torch.cos(ts / (1 + s) * math.pi / 2).pow(2)
+        al = al / al[0]
+        return (1 - al[1:] / al[:-1]).clamp(max=0.999).numpy()
+    raise NotImplementedError(schedule)
+
+
+def schedule_tables(schedule_opt: dict) -> Dict[str, np.ndarray]:
+    """model/diffusion.py:101-148.  fp32 tables + the float64 ``sqrt_alphas_cumprod_prev``."""
+    betas = make_betas(schedule_opt["schedule"], schedule_opt["n_timestep"],
+                       schedule_opt["linear_start"], schedule_opt["linear_end"])
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    return {
+        "betas": f32(betas),
+        "alphas_cumprod": f32(ac),
+        "alphas_cumprod_prev": f32(ac_prev),
+        "sqrt_alphas_cumprod": f32(np.sqrt(ac)),
+        "sqrt_one_minus_alphas_cumprod": f32(np.sqrt(1.0 - ac)),
+        "log_one_minus_alphas_cumprod": f32(np.log(1.0 - ac)),
+        "sqrt_recip_alphas_cumprod": f32(np.sqrt(1.0 / (ac + 1e-10))),
+        "sqrt_recipm1_alphas_cumprod": f32(np.sqrt(1.0 / (ac + 1e-10) - 1)),
+        "posterior_variance": f32(pv),
+        "posterior_log_variance_clipped": f32(np.log(np.maximum(pv, 1e-20))),
+        "posterior_mean_coef1": f32(betas * np.sqrt(ac_prev) / (1.0 - ac)),
+        "posterior_mean_coef2": f32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)),
+        "sqrt_alphas_cumprod_prev": np.sqrt(np.append(1.0, ac)),  # float64, len T+1 (diffusion.py:114-115)
+    }
+
+
+# ----------------------------------------------------------------------------------------------
+# DY3h pieces (model/ucdir.py)
+# ----------------------------------------------------------------------------------------------
+def swish(x):  # model/ucdir.py:48-50
+    return x * torch.sigmoid(x)
+
+
+def noise_embedding(sd: SD, level: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """PositionalEncoding + MLP (model/ucdir.py:24-29, 212-214).  level (B,1) -> (B,1,inner)."""
+    w1 = sd[prefix + "noise_level_mlp.1.weight"]
+    dim = w1.shape[1]
+    half = dim // 2
+    step = torch.arange(half, dtype=level.dtype) / half
+    enc = level.unsqueeze(1) * torch.exp(-math.log(1e4) * step.unsqueeze(0))
+    enc = torch.cat([torch.sin(enc), torch.cos(enc)], dim=-1)
+    h = F.linear(enc, w1, sd[prefix + "noise_level_mlp.1.bias"])
+    h = swish(h)
+    return F.linear(h, sd[prefix + "noise_level_mlp.3.weight"], sd[prefix + "noise_level_mlp.3.bias"])
+
+
+def guide_resample(guide: torch.Tensor, w: int) -> torch.Tensor:
+    """model/ucdir.py:133-134: bilinear, align_corners=False, scale_factor = w / guide_w."""
+    ratio = w / guide.shape[-1]
+    return F.interpolate(guide, scale_factor=ratio, mode="bilinear", align_corners=False)
+
+
+def guide_branch(sd: SD, p: str, guide: torch.Tensor, w: int) -> torch.Tensor:
+    """conv2 of the integration module on the resampled guide (model/ucdir.py:113-114,134-135),
+    *without* the time weights.  Returns (B, 8, h, w)."""
+    g = guide_resample(guide, w)
+    a = F.conv2d(g, sd[p + "conv2.0.weight"], sd[p + "conv2.0.bias"])
+    a1, a2 = a.chunk(2, dim=1)          # SimpleGate, model/ucdir.py:149-152
+    return F.conv2d(a1 * a2, sd[p + "conv2.2.weight"], sd[p + "conv2.2.bias"], padding=1)
+
+
+def time_weights(sd: SD, p: str, temb: torch.Tensor) -> torch.Tensor:
+    """noise_func of a block (model/ucdir.py:106,125): (B,1,inner) -> (B,8)."""
+    h = F.linear(temb, sd[p + "noise_func.0.weight"], sd[p + "noise_func.0.bias"])
+    h = swish(h)
+    h = F.linear(h, sd[p + "noise_func.2.weight"], sd[p + "noise_func.2.bias"])
+    return h.reshape(temb.shape[0], -1)
+
+
+def resblock_dy3h(sd: SD, p: str, x: torch.Tensor, temb: torch.Tensor, guide: torch.Tensor,
+                  taps: Optional[dict] = None) -> torch.Tensor:
+    """ResnetBlockDY3h.forward (model/ucdir.py:122-140).  ``p`` ends with 'res_block.'."""
+    B, _, H, W = x.shape
+    attw = time_weights(sd, p, temb)
+    h = F.group_norm(x, 1, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-5)
+    h = F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = swish(h)
+    if taps is not None:
+        taps[p + "h1"] = h
+    h = F.group_norm(h, 1, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-5)
+    att_sp = guide_branch(sd, p, guide, W) * attw.view(B, -1, 1, 1)
+    wsp = sd[p + "spdyconv.weight"]
+    cout = wsp.shape[0] // att_sp.shape[1]
+    hset = F.conv2d(h, wsp, sd[p + "spdyconv.bias"], padding=1, groups=att_sp.shape[1])
+    hset = hset.view(B, cout, att_sp.shape[1], H, W)
+    h = (hset * att_sp.unsqueeze(1)).sum(dim=2)
+    h = swish(h)
+    if (p + "res_conv.weight") in sd:
+        res = F.conv2d(x, sd[p + "res_conv.weight"], sd[p + "res_conv.bias"])
+    else:
+        res = x
+    return h + res
+
+
+def self_attention(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """SelfAttention.forward, n_head = 1 (model/ucdir.py:165-182).  ``p`` ends with 'attn.'."""
+    B, C, H, W = x.shape
+    n = F.group_norm(x, 1, sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-5)
+    qkv = F.conv2d(n, sd[p + "qkv.weight"])
+    q, k, v = qkv.reshape(B, 3, C, H * W).unbind(dim=1)          # each (B, C, N)
+    att = torch.bmm(q.transpose(1, 2), k) / math.sqrt(C)          # (B, Nq, Nk)
+    att = torch.softmax(att, dim=-1)
+    out = torch.bmm(v, att.transpose(1, 2)).reshape(B, C, H, W)   # out[c,i] = sum_j att[i,j] v[c,j]
+    out = F.conv2d(out, sd[p + "out.weight"], sd[p + "out.bias"])
+    return out + x
+
+
+def _layer_plan(sd: SD, prefix: str) -> Tuple[List[Tuple[str, str]], List[Tuple[str, str]], List[Tuple[str, str]]]:
+    """Recover (kind, name) lists for downs / mid / ups from the keys present."""
+    def scan(group):
+        out = []
+        i = 0
+        while True:
+            base = f"{prefix}{group}.{i}."
+            if (base + "res_block.conv1.weight") in sd:
+                out.append(("block", base))
+            elif (base + "conv.weight") in sd:
+                out.append(("resample", base))
+            elif (base + "weight") in sd:
+                out.append(("stem", base))
+            else:
+                break
+            i += 1
+        return out
+    return scan("downs"), scan("mid"), scan("ups")
+
+
+def dy3h_naive_forward(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torch.Tensor,
+                       prefix: str = "denoise_fn.", taps: Optional[dict] = None) -> torch.Tensor:
+    """DY3h.naiveforward (model/ucdir.py:270-293)."""
+    temb = noise_embedding(sd, level, prefix)
+    downs, mid, ups = _layer_plan(sd, prefix)
+    feats = []
+
+    def run_block(base, x):
+        x = resblock_dy3h(sd, base + "res_block.", x, temb, guide, taps)
+        if (base + "attn.qkv.weight") in sd:
+            x = self_attention(sd, base + "attn.", x)
+        if taps is not None:
+            taps[base[:-1]] = x
+        return x
+
+    for kind, base in downs:
+        if kind == "stem":
+            x = F.conv2d(x, sd[base + "weight"], sd[base + "bias"], padding=1)
+            if taps is not None:
+                taps[base[:-1]] = x
+        elif kind == "resample":      # Downsample: conv 3x3 stride 2 pad 1 (model/ucdir.py:63-69)
+            x = F.conv2d(x, sd[base + "conv.weight"], sd[base + "conv.bias"], stride=2, padding=1)
+            if taps is not None:
+                taps[base[:-1]] = x
+        else:
+            x = run_block(base, x)
+        feats.append(x)
+    for kind, base in mid:
+        x = run_block(base, x)
+    for kind, base in ups:
+        if kind == "resample":        # Upsample: nearest x2 then conv 3x3 (model/ucdir.py:53-60)
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            x = F.conv2d(x, sd[base + "conv.weight"], sd[base + "conv.bias"], padding=1)
+            if taps is not None:
+                taps[base[:-1]] = x
+        else:
+            x = run_block(base, torch.cat((x, feats.pop()), dim=1))
+    # final_conv: GroupNorm(1) -> Swish -> (Dropout = identity in eval) -> conv3x3 (model/ucdir.py:266-268)
+    h = F.group_norm(x, 1, sd[prefix + "final_conv.0.weight"], sd[prefix + "final_conv.0.bias"], eps=1e-5)
+    return F.conv2d(swish(h), sd[prefix + "final_conv.3.weight"], sd[prefix + "final_conv.3.bias"], padding=1)
+
+
+def pad32(n: int) -> int:
+    return (n // 32 + 1) * 32 - n      # model/ucdir.py:303-304 (always 1..32)
+
+
+def patch_windows(H: int, W: int, skip: int, padding: int):
+    """Window list of utils/util.py:119-137 for a *padded* canvas of H x W.
+    Returns [(h0, h1, w0, w1)] in evaluation order (later windows overwrite earlier ones)."""
+    shift = skip - 2 * padding
+    out = []
+    for i in range(0, H, shift):
+        for j in range(0, W, shift):
+            h0, h1, w0, w1 = i, i + skip, j, j + skip
+            if h1 > H:
+                h1, h0 = H, H - skip
+            if w1 > W:
+                w1, w0 = W, W - skip
+            out.append((h0, h1, w0, w1))
+    return out
+
+
+def patch_forward_guide(x: torch.Tensor, net, level, guide, skip: int, padding: int) -> torch.Tensor:
+    """utils/util.py:108-146 with ``net(x, level, guide)``."""
+    pd = min(x.shape[-1], x.shape[-2])
+    pd = skip - pd + padding if pd < skip else padding
+    xp = F.pad(x, (pd, pd, pd, pd), mode="reflect")
+    gp = F.pad(guide, (pd, pd, pd, pd), mode="reflect")
+    out = torch.zeros_like(xp)[:, :3]
+    _, _, H, W = xp.shape
+    for (h0, h1, w0, w1) in patch_windows(H, W, skip, padding):
+        o = net(xp[..., h0:h1, w0:w1], level, gp[..., h0:h1, w0:w1])
+        out[..., h0 + padding:h1 - padding, w0 + padding:w1 - padding] = o[..., padding:-padding, padding:-padding]
+    return out[..., pd:-pd, pd:-pd]
+
+
+def dy3h_forward(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torch.Tensor,
+                 prefix: str = "denoise_fn.", patch_threshold: int = 1024 * 1024,
+                 skip: int = 1024, padding: int = 64) -> torch.Tensor:
+    """DY3h.forward (model/ucdir.py:295-307)."""
+    _, _, h, w = x.shape
+    if h * w > patch_threshold:
+        net = lambda xx, ll, gg: dy3h_naive_forward(sd, xx, ll, gg, prefix)
+        return patch_forward_guide(x, net, level, guide, skip, padding)
+    ph, pw = pad32(h), pad32(w)
+    xp = F.pad(x, (0, pw, 0, ph), mode="reflect")
+    gp = F.pad(guide, (0, pw, 0, ph), mode="reflect")
+    return dy3h_naive_forward(sd, xp, level, gp, prefix)[..., :-ph, :-pw]
+
+
+# ----------------------------------------------------------------------------------------------
+# UNetSeeInDark predictor (model/ucdir.py:352-416)
+# ----------------------------------------------------------------------------------------------
+def predictor_forward(sd: SD, x: torch.Tensor, prefix: str = "predictor.") -> torch.Tensor:
+    _, _, h, w = x.shape
+    ph, pw = pad32(h), pad32(w)
+    x = F.pad(x, (0, pw, 0, ph), mode="reflect")
+    lrelu = lambda t: torch.max(0.2 * t, t)
+    c3 = lambda t, n: lrelu(F.conv2d(t, sd[prefix + n + ".weight"], sd[prefix + n + ".bias"], padding=1))
+    enc = []
+    t = x
+    for lvl in range(1, 5):
+        t = c3(c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
+        enc.append(t)
+        t = F.max_pool2d(t, 2)
+    t = c3(c3(t, "conv5_1"), "conv5_2")
+    for lvl in range(6, 10):
+        t = F.conv_transpose2d(t, sd[prefix + f"upv{lvl}.weight"], sd[prefix + f"upv{lvl}.bias"], stride=2)
+        t = torch.cat([t, enc.pop()], dim=1)
+        t = c3(c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
+    out = F.conv2d(t, sd[prefix + "conv10_1.weight"], sd[prefix + "conv10_1.bias"])
+    return out[..., :-ph, :-pw]
+
+
+# ----------------------------------------------------------------------------------------------
+# sampler (model/diffusion.py:150-211, 473-478)
+# ----------------------------------------------------------------------------------------------
+def p_sample_step(tab: dict, x_t: torch.Tensor, eps: torch.Tensor, t: int, noise: Optional[torch.Tensor]):
+    """predict_start_from_noise + clamp + q_posterior + sampling (diffusion.py:150-158, 171-183)."""
+    T = lambda k: torch.tensor(tab[k][t], dtype=torch.float32)
+    x0 = T("sqrt_recip_alphas_cumprod") * x_t - T("sqrt_recipm1_alphas_cumprod") * eps
+    x0 = x0.clamp(-1.0, 1.0)
+    mean = T("posterior_mean_coef1") * x0 + T("posterior_mean_coef2") * x_t
+    if t > 0:
+        return mean + noise * (0.5 * T("posterior_log_variance_clipped")).exp()
+    return mean
+
+
+def noise_level_for(tab: dict, t: int, B: int) -> torch.Tensor:
+    """diffusion.py:162-163."""
+    return torch.FloatTensor([tab["sqrt_alphas_cumprod_prev"][t + 1]]).repeat(B, 1)
+
+
+def p_sample_loop(sd: SD, tab: dict, cond: torch.Tensor, guide: torch.Tensor,
+                  noises: Sequence[torch.Tensor], continous: bool = False, **fw) -> torch.Tensor:
+    """diffusion.py:185-211 (conditional branch) with injected noise:
+    noises[0] = x_T, then one tensor per step with t > 0 in loop order."""
+    T = len(tab["betas"])
+    inter = 1 | (T // 10)
+    img = noises[0]
+    ret = cond
+    k = 1
+    for t in reversed(range(T)):
+        lvl = noise_level_for(tab, t, cond.shape[0])
+        eps = dy3h_forward(sd, torch.cat([cond, img], dim=1), lvl, guide, **fw)
+        nz = None
+        if t > 0:
+            nz = noises[k]
+            k += 1
+        img = p_sample_step(tab, img, eps, t, nz)
+        if t % inter == 0:
+            ret = torch.cat([ret, img], dim=0)
+    return ret if continous else ret[-1]
+
+
+def super_resolution(sd: SD, tab: dict, x_in: torch.Tensor, noises, continous: bool = False, **fw):
+    """ResiGaussianGuideDY.super_resolution (diffusion.py:473-478)."""
+    initx = predictor_forward(sd, x_in)
+    return p_sample_loop(sd, tab, x_in, initx, noises, continous, **fw) + initx
+
+
+def ddpm_test(sd: SD, tab: dict, sr: torch.Tensor, noises, continous: bool = False, **fw):
+    """DDPM.test caller semantics (model/model.py:124-138): reflect-pad 64, restore, crop."""
+    pd = 64
+    out = super_resolution(sd, tab, F.pad(sr, (pd, pd, pd, pd), mode="reflect"), noises, continous, **fw)
+    return out[..., pd:-pd, pd:-pd]
+
+
+def tensor2img(t: torch.Tensor) -> np.ndarray:
+    """core/metrics.py:14-34 for a single (3,H,W) / (1,3,H,W) image: clamp, [-1,1] -> uint8 HWC RGB."""
+    t = t.squeeze().float().clamp(-1, 1)
+    t = (t + 1) / 2
+    img = t.numpy().transpose(1, 2, 0)
+    return (img * 255.0).round().astype(np.uint8)
+
+
+def psnr(img1: np.ndarray, img2: np.ndarray) -> float:
+    """core/metrics.py:48-55."""
+    mse = np.mean((img1.astype(np.float64) - img2.astype(np.float64)) ** 2)
+    if mse == 0:
+        return float("inf")
+    return 20 * math.log10(255.0 / math.sqrt(mse))
+
+
+def to_torch_sd(np_sd: dict) -> SD:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in np_sd.items()}
