@@ -1,0 +1,133 @@
+/*
+ * ucdir_hip.h — C ABI of libucdir_hip.so, the MI355X (gfx950) denoiser engine.
+ *
+ * Drop-in boundary: this library replaces the *inner operator* that the reference's
+ * sampler calls once per DDPM step,
+ *
+ *     denoise_fn(cat[cond, x_t] (B,6,H,W), noise_level (B,1), guide=(B,3,H,W)) -> eps (B,3,H,W)
+ *         reference: model/diffusion.py:166 (call site), model/ucdir.py:295-307 (DY3h.forward),
+ *                    model/ucdir.py:270-293 (DY3h.naiveforward)
+ *
+ * plus the point-wise ancestral update around it (model/diffusion.py:150-158,171-183).
+ * The reference has no FFI of its own (it is pure Python/PyTorch), so the entry points below
+ * are what a ctypes binding added to the reference's `model/networks.py:define_G` would
+ * bind; INTEGRATION.md shows that stub.
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw device pointers, sizes; no C++/torch types cross the ABI;
+ *   - every function returns 0 on success, non-zero on error; ucdir_last_error() describes
+ *     the last failure on the calling thread;
+ *   - all tensor arguments are DEVICE pointers unless the name ends in `_host`;
+ *   - tensors crossing the ABI use the reference's layout: NCHW, fp32, contiguous;
+ *   - all work is enqueued on the hipStream_t passed in (as void*) and is asynchronous;
+ *   - a handle is not thread-safe (one handle per device / per process, like the reference's
+ *     one-process-per-GPU use); the library owns packed weights + workspace, the caller owns
+ *     every tensor it passes in.
+ */
+#ifndef UCDIR_HIP_H
+#define UCDIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCDIR_ABI_VERSION 1
+#define UCDIR_MAX_MULTS 8
+
+typedef struct ucdir_ctx ucdir_ctx;
+
+/* Mirrors the `model.unet` section of config/sid.yaml:41-56 (reference: DY3h.__init__,
+ * model/ucdir.py:205-207). */
+typedef struct ucdir_config {
+    int32_t in_channel;                     /* 6  = cat[cond(3), x_t(3)]            */
+    int32_t out_channel;                    /* 3                                     */
+    int32_t inner_channel;                  /* 64 (must be a multiple of 64)         */
+    int32_t n_mults;
+    int32_t channel_mults[UCDIR_MAX_MULTS]; /* 1,2,4,8,8                             */
+    int32_t n_attn_res;
+    int32_t attn_res[UCDIR_MAX_MULTS];      /* 16                                    */
+    int32_t res_blocks;                     /* 2                                     */
+    int32_t image_size;                     /* 128 (only used to place attention)    */
+    int32_t device;                         /* HIP device ordinal                    */
+} ucdir_config;
+
+int32_t     ucdir_abi_version(void);
+const char* ucdir_last_error(void);
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int32_t ucdir_create(const ucdir_config* cfg, ucdir_ctx** out);
+void    ucdir_destroy(ucdir_ctx* ctx);
+
+/* ---- weights (replaces nn.Module.load_state_dict for denoise_fn.*, model/model.py:224-251) --
+ * `name` is the reference state_dict key without the "denoise_fn." prefix
+ * (e.g. "downs.4.res_block.conv1.weight"); `data_host` is fp32, reference shape. After all
+ * tensors are supplied, ucdir_finalize_weights folds GroupNorm affines into the following
+ * convolution, converts to bf16 MFMA layouts and uploads. */
+int32_t ucdir_load_weight(ucdir_ctx* ctx, const char* name, const float* data_host,
+                          const int64_t* shape, int32_t ndim);
+int32_t ucdir_finalize_weights(ucdir_ctx* ctx);
+/* number of parameter tensors the config expects / the i-th expected name */
+int32_t     ucdir_num_weights(const ucdir_ctx* ctx);
+const char* ucdir_weight_name(const ucdir_ctx* ctx, int32_t i);
+
+/* ---- per-image state: the guide branch of every block (model/ucdir.py:133-135) does not
+ * depend on t or x_t, so it is evaluated once per image.  guide: (B,3,H,W) fp32.
+ * `pad_mode` 1 = DY3h.forward semantics (reflect-pad bottom/right to (d/32+1)*32, crop on
+ * output; model/ucdir.py:303-307); 0 = naiveforward (H, W multiples of 32; used for the windows
+ * of the inter-step patch split, utils/util.py:108-146). Allocates workspace on first use /
+ * on shape change. */
+int32_t ucdir_prepare_guide(ucdir_ctx* ctx, const float* guide, int32_t B, int32_t H, int32_t W,
+                            int32_t pad_mode, void* stream);
+
+/* ---- the denoiser: eps = DY3h(cat[cond, x_t], noise_level, guide) ----------------------
+ * cond, x_t: (B,3,H,W) fp32 (the channel concat of model/diffusion.py:166 is done on the fly);
+ * noise_level: (B) fp32; eps: (B,3,H,W) fp32.  Shapes must match the last prepare_guide. */
+int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t,
+                           const float* noise_level, float* eps, void* stream);
+
+/* ---- ancestral sampler update (model/diffusion.py:150-158,171-183), in place on x_t:
+ *   x0   = clamp(c_recip * x_t - c_recipm1 * eps, -1, 1)
+ *   x_t <- coef1 * x0 + coef2 * x_t + sigma * noise      (noise may be NULL when sigma == 0)
+ * n = number of fp32 elements. */
+int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int64_t n,
+                           float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
+                           void* stream);
+
+/* ---- introspection (tests / profiling) ---------------------------------------------------
+ * Copy the activation a layer produced in the last forward into dst as (B,C,Hc,Wc) fp32 NCHW
+ * (Hc, Wc = compute size).  layer = state_dict prefix ("downs.0", "ups.7", "mid.0", ...),
+ * what = "out" (layer output) or "h1" (swish(conv1) inside a block). */
+int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst,
+                         int64_t dst_elems, void* stream);
+int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
+/* algorithmic FLOPs of one forward at the prepared shape (2*MAC, reference op count) */
+double  ucdir_forward_flops(const ucdir_ctx* ctx);
+
+/* ---- single-operator entry points (unit parity tests; fp32 NCHW in/out, bf16 inside) -----
+ * conv: y = act(conv(GN?(cat[x0,x1]))) with 3x3 (mode 0 stride 1, 1 stride-2 down,
+ * 2 nearest-x2-up then 3x3) or 1x1 (ksize 1).  gamma/beta NULL = no GroupNorm fold. */
+int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1,
+                      int32_t B, int32_t H, int32_t W,
+                      const float* w_host, const float* bias_host,
+                      const float* gamma_host, const float* beta_host,
+                      int32_t cout, int32_t ksize, int32_t mode, int32_t silu,
+                      const float* residual, float* y, double* stats_out_host, void* stream);
+/* AKGM block tail: y = swish(sum_s spdyconv(GN2(h))[c,s] * att[s]) + res
+ * h: (B,C,H,W); att: (B,8,H,W) (= conv2(guide) * attw, already multiplied); res: (B,C,H,W) */
+int32_t ucdir_op_akgm(const float* h, const float* att, const float* res,
+                      int32_t B, int32_t C, int32_t H, int32_t W,
+                      const float* wsp_host, const float* bsp_host,
+                      const float* gamma_host, const float* beta_host,
+                      float* y, void* stream);
+/* SelfAttention.forward (model/ucdir.py:165-182): y = out(softmax(q^T k / sqrt(C)) v) + x */
+int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int32_t W,
+                           const float* gamma_host, const float* beta_host,
+                           const float* wqkv_host, const float* wout_host, const float* bout_host,
+                           float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCDIR_HIP_H */

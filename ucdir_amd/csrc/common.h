@@ -1,0 +1,72 @@
+// Shared device/host definitions for libucdir_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// round-to-nearest-even float -> bf16 (inputs are finite on this path)
+__host__ __device__ inline bf16_t f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    uint32_t u = v.u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf2f(bf16_t h) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+
+__device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// Activation tensor in HBM: zero-bordered NHWC bf16, [B][H+2][W+2][C].  The one-pixel zero
+// border makes every 3x3 tap of an interior pixel an in-bounds read of the right value, so the
+// implicit GEMM needs no per-tap predication.  Borders are zeroed once and never written.
+struct Act {
+    bf16_t* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    double* stats = nullptr;       // [B][2] (sum, sum of squares) over the valid region
+    float* partials = nullptr;     // [B][npart][2] per-workgroup partial sums
+    int npart = 0;
+    __host__ __device__ int Hp() const { return H + 2; }
+    __host__ __device__ int Wp() const { return W + 2; }
+    long long bstride() const { return (long long)(H + 2) * (W + 2) * C; }
+    long long elems() const { return bstride() * B; }
+};
+
+enum { COLS_S1 = 0, COLS_DOWN = 1, COLS_UP = 2, COLS_PLAIN = 3 };
+enum { EPI_STD = 0, EPI_AKGM = 1 };
+
+// Parameters of one implicit-GEMM launch:  D[row][col] = sum_k A[row][k] * Bm[col][k]
+//   rows = output features (weights) or tokens, cols = pixel positions or tokens.
+struct GemmP {
+    // A operand: row-major [rows][a_ld] bf16, K contiguous
+    const bf16_t* A; long long a_bstride; long long a_gstride; int a_ld; int a_rows;
+    // B operand: up to two NHWC sources concatenated along channels
+    const bf16_t* B0; const bf16_t* B1; long long b0_bstride, b1_bstride; int ld0, ld1; int c0;
+    int cols_mode; int in_compact;
+    int H, W, Wp;            // column grid (valid H x W, padded width Wp); PLAIN: ncols = W
+    int Hi, Wi, Wpi;         // input grid (DOWN / UP / compact-in)
+    int p0, pn;              // first column position and number of positions per sample
+    int ntaps, cpt, cpt_shift, cg;   // taps (1|9), 16-byte chunks per tap, log2(cpt) if cpt<8, channels/group
+    int nk;                  // K steps of 64
+    int tiles;               // column tiles per sample
+    int rowtiles;            // row tiles (grid.y equivalent)
+    int groups_per_wg;       // AKGM: groups looped inside one workgroup
+    int nbatch;
+    // epilogue
+    float alpha; int fold; int act;
+    const double* stats0; const double* stats1; double inv_count;   // GN of the input (fold)
+    const float* bias; const float* Tb; const float* Tg; int tab_ld;  // tables [ncls][tab_ld]
+    const bf16_t* res; long long res_bstride; int res_ld; int res_coff;
+    void* out; long long out_bstride; int out_ld; int out_coff; int out_f32; int out_compact;
+    int nfeat;               // valid output features (rows) in total
+    float* partials; int npart;
+    // AKGM
+    const float* G; long long g_bstride;   // guide branch, compact [B][H*W][8]
+    const float* attw;                      // [B][8]
+};

@@ -1,0 +1,826 @@
+// libucdir_hip: context, weights, workspace and the DY3h forward as a chain of HIP launches.
+// Reference semantics: model/ucdir.py:270-307 (DY3h), :122-140 (block), :165-182 (attention).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ucdir_hip.h"
+#include "cgemm.hip.h"
+#include "common.h"
+#include "misc.hip.h"
+#include "pack.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPC(x)                                                                                   \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_));             \
+        }                                                                                         \
+    } while (0)
+#define API_BEGIN try {
+#define API_END                                                                                   \
+    }                                                                                             \
+    catch (const std::exception& e) { return fail(e.what()); }                                    \
+    catch (...) { return fail("unknown error"); }                                                 \
+    return 0;
+
+static void require(bool c, const std::string& m) { if (!c) throw std::runtime_error(m); }
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers (library-owned buffers)
+// ------------------------------------------------------------------------------------------------
+struct DevPool {
+    std::vector<void*> ptrs;
+    int64_t bytes = 0;
+    void* alloc(size_t n, bool zero = true) {
+        void* p = nullptr;
+        if (n == 0) n = 16;
+        HIPC(hipMalloc(&p, n));
+        if (zero) HIPC(hipMemset(p, 0, n));
+        ptrs.push_back(p); bytes += (int64_t)n;
+        return p;
+    }
+    template <typename T> T* upload(const std::vector<T>& v) {
+        T* p = (T*)alloc(v.size() * sizeof(T), false);
+        if (!v.empty()) HIPC(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); bytes = 0; }
+    ~DevPool() { release(); }
+};
+
+struct ConvW {
+    bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
+    int rows_pad = 0, Kpad = 0, ntaps = 0, cin = 0, cout = 0, TM = 128; bool fold = false;
+};
+struct AkgmW {
+    bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
+    int C = 0, cg = 0, Kpad = 0;
+};
+
+static int pick_tm(int cout) { return cout >= 128 ? 128 : 64; }
+
+static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const float* gamma, const float* beta,
+                         int cout, int cin, int ks) {
+    ConvW W;
+    W.TM = pick_tm(cout);
+    PackedConv P = pack_conv(w, bias, gamma, beta, cout, cin, ks, W.TM);
+    W.A = pool.upload(P.A); W.bias = pool.upload(P.bias);
+    W.fold = gamma != nullptr;
+    if (W.fold) { W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg); }
+    W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
+    return W;
+}
+static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
+    PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C);
+    AkgmW W;
+    W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
+    W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
+    return W;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <int TM, int EPI, int MODE>
+static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(hipFuncSetAttribute((const void*)cgemm_kernel<TM, EPI, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((cgemm_kernel<TM, EPI, MODE>), grid, dim3(CG_THREADS), lds, st, p);
+}
+
+static void launch_cgemm(const GemmP& p, int TM, int epi, hipStream_t st) {
+    const int nblk = p.nbatch * p.tiles * p.rowtiles;
+    const size_t lds = cgemm_lds_bytes(TM, epi, p.groups_per_wg);
+    dim3 grid(nblk);
+    int mode = p.cols_mode;
+    if (mode == COLS_S1 && p.in_compact) mode = MODE_S1C;
+    if (epi == EPI_AKGM) {
+        if (TM == 128) launch_one<128, EPI_AKGM, MODE_S1>(p, grid, lds, st); else launch_one<64, EPI_AKGM, MODE_S1>(p, grid, lds, st);
+    } else if (TM == 128) {
+        switch (mode) {
+            case MODE_S1: launch_one<128, EPI_STD, MODE_S1>(p, grid, lds, st); break;
+            case MODE_DOWN: launch_one<128, EPI_STD, MODE_DOWN>(p, grid, lds, st); break;
+            case MODE_UP: launch_one<128, EPI_STD, MODE_UP>(p, grid, lds, st); break;
+            case MODE_PLAIN: launch_one<128, EPI_STD, MODE_PLAIN>(p, grid, lds, st); break;
+            default: launch_one<128, EPI_STD, MODE_S1C>(p, grid, lds, st); break;
+        }
+    } else {
+        switch (mode) {
+            case MODE_S1: launch_one<64, EPI_STD, MODE_S1>(p, grid, lds, st); break;
+            case MODE_DOWN: launch_one<64, EPI_STD, MODE_DOWN>(p, grid, lds, st); break;
+            case MODE_UP: launch_one<64, EPI_STD, MODE_UP>(p, grid, lds, st); break;
+            case MODE_PLAIN: launch_one<64, EPI_STD, MODE_PLAIN>(p, grid, lds, st); break;
+            default: launch_one<64, EPI_STD, MODE_S1C>(p, grid, lds, st); break;
+        }
+    }
+    HIPC(hipGetLastError());
+}
+
+static void set_kernel_attrs() {}
+
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+static void zero_gemm(GemmP& p) { std::memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.groups_per_wg = 1; }
+
+static void finalize_stats(Act& y, hipStream_t st) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(y.B), dim3(256), 0, st, y.partials, y.npart, y.stats);
+    HIPC(hipGetLastError());
+}
+
+// npart upper bound for an activation produced by any cgemm configuration (TM >= 64)
+static int npart_for(int H, int W, int C) {
+    const int pn = (H - 1) * (W + 2) + W;
+    const int tiles = (pn + CG_TP - 1) / CG_TP;
+    int rt = (C + 63) / 64;
+    if (C / 16 > rt) rt = C / 16;          // AKGM launches 8*C/128 row tiles
+    int stem_blocks = ((H * W + 255) / 256) * ((C + 63) / 64);
+    int n = tiles * rt;
+    return n > stem_blocks ? n : stem_blocks;
+}
+
+static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats = true) {
+    Act a; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.p = (bf16_t*)pool.alloc((size_t)a.elems() * sizeof(bf16_t), true);
+    if (with_stats) {
+        a.npart = npart_for(H, W, C);
+        a.partials = (float*)pool.alloc((size_t)B * a.npart * 2 * sizeof(float), true);
+        a.stats = (double*)pool.alloc((size_t)B * 2 * sizeof(double), true);
+    }
+    return a;
+}
+
+// conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
+static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
+                     bool want_stats, hipStream_t st) {
+    GemmP p; zero_gemm(p);
+    const int cin = x0.C + (x1 ? x1->C : 0);
+    require(cin == w.cin, "run_conv: channel mismatch");
+    require(y.C == w.cout, "run_conv: cout mismatch");
+    p.A = w.A; p.a_ld = w.Kpad; p.a_rows = w.rows_pad;
+    p.B0 = x0.p; p.b0_bstride = x0.bstride(); p.ld0 = x0.C; p.c0 = x0.C;
+    if (x1) { p.B1 = x1->p; p.b1_bstride = x1->bstride(); p.ld1 = x1->C; }
+    p.cols_mode = mode;
+    p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
+    p.Hi = x0.H; p.Wi = x0.W; p.Wpi = x0.W + 2;
+    p.p0 = p.Wp + 1; p.pn = (y.H - 1) * p.Wp + y.W;
+    p.ntaps = w.ntaps; p.cg = cin; p.cpt = cin / 8; p.cpt_shift = 0;
+    p.nk = w.Kpad / CG_BK;
+    p.tiles = (p.pn + CG_TP - 1) / CG_TP;
+    p.rowtiles = w.rows_pad / w.TM;
+    p.nbatch = y.B;
+    p.fold = w.fold ? 1 : 0; p.act = act;
+    if (w.fold) {
+        p.stats0 = x0.stats; p.stats1 = x1 ? x1->stats : nullptr;
+        p.inv_count = 1.0 / ((double)cin * x0.H * x0.W);
+        p.Tb = w.Tb; p.Tg = w.Tg; p.tab_ld = w.cout;
+    }
+    p.bias = w.bias;
+    if (res) { p.res = res->p; p.res_bstride = res->bstride(); p.res_ld = res->C; p.res_coff = 0; }
+    p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = y.C; p.nfeat = w.cout;
+    if (want_stats) {
+        p.npart = p.tiles * p.rowtiles;
+        require(p.npart <= y.npart, "run_conv: partial buffer too small");
+        p.partials = y.partials;
+    }
+    launch_cgemm(p, w.TM, EPI_STD, st);
+    if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
+}
+
+// AKGM tail of a block: y = swish(sum_s spdyconv(GN2(h1))[c,s] * G[s] * attw[s]) + res
+static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y,
+                     hipStream_t st) {
+    GemmP p; zero_gemm(p);
+    const int C = w.C;
+    require(C == 64 || C % 128 == 0, "AKGM: channel count must be 64 or a multiple of 128");
+    const int TM = (C == 64) ? 64 : 128;
+    p.A = w.A; p.a_ld = w.Kpad; p.a_rows = C; p.a_gstride = (long long)C * w.Kpad;
+    p.B0 = h1.p; p.b0_bstride = h1.bstride(); p.ld0 = C; p.c0 = C;
+    p.cols_mode = COLS_S1;
+    p.H = y.H; p.W = y.W; p.Wp = y.W + 2; p.Hi = y.H; p.Wi = y.W; p.Wpi = p.Wp;
+    p.p0 = p.Wp + 1; p.pn = (y.H - 1) * p.Wp + y.W;
+    p.ntaps = 9; p.cg = w.cg; p.cpt = w.cg / 8; p.cpt_shift = ilog2(p.cpt);
+    p.nk = w.Kpad / CG_BK;
+    p.tiles = (p.pn + CG_TP - 1) / CG_TP;
+    p.groups_per_wg = (C == 64) ? 8 : 1;
+    p.rowtiles = (C == 64) ? 1 : 8 * (C / TM);
+    p.nbatch = y.B;
+    p.fold = 1; p.act = 1;
+    p.stats0 = h1.stats; p.inv_count = 1.0 / ((double)C * h1.H * h1.W);
+    p.bias = w.bias; p.Tb = w.Tb; p.Tg = w.Tg; p.tab_ld = 8 * C;
+    p.res = res.p; p.res_bstride = res.bstride(); p.res_ld = res.C; p.res_coff = 0;
+    p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
+    p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
+    p.npart = p.tiles * p.rowtiles;
+    require(p.npart <= y.npart, "run_akgm: partial buffer too small");
+    p.partials = y.partials;
+    launch_cgemm(p, TM, EPI_AKGM, st);
+    y.npart = p.npart; finalize_stats(y, st);
+}
+
+struct AttnBufs {
+    bf16_t* qkv = nullptr;   // [B][N][3C]
+    float* S = nullptr;      // [B][N][Npad]
+    bf16_t* P = nullptr;     // [B][N][Npad]
+    bf16_t* Vt = nullptr;    // [B][C][Npad]
+    bf16_t* O = nullptr;     // [B][N][C]
+    int N = 0, Npad = 0, C = 0, B = 0;
+};
+
+static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C) {
+    a.B = B; a.N = N; a.C = C; a.Npad = ((N + 63) / 64) * 64;
+    a.qkv = (bf16_t*)pool.alloc((size_t)B * N * 3 * C * 2);
+    a.S = (float*)pool.alloc((size_t)B * N * a.Npad * 4);
+    a.P = (bf16_t*)pool.alloc((size_t)B * N * a.Npad * 2);
+    a.Vt = (bf16_t*)pool.alloc((size_t)B * C * a.Npad * 2);
+    a.O = (bf16_t*)pool.alloc((size_t)B * N * C * 2);
+}
+
+// SelfAttention (model/ucdir.py:165-182): y = out(softmax(q^T k / sqrt(C)) v) + x
+static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Act& y, AttnBufs& a, hipStream_t st) {
+    const int C = x.C, N = x.H * x.W, B = x.B, Npad = ((N + 63) / 64) * 64;
+    require(C % 128 == 0, "attention: channels must be a multiple of 128");
+    require(N % 8 == 0, "attention: token count must be a multiple of 8");
+    require((size_t)N <= (size_t)a.N && C == a.C && B <= a.B, "attention buffers too small");
+    // 1. q,k,v = conv1x1(GN(x))   (GroupNorm folded; output compact [B][N][3C])
+    {
+        GemmP p; zero_gemm(p);
+        p.A = wqkv.A; p.a_ld = wqkv.Kpad; p.a_rows = wqkv.rows_pad;
+        p.B0 = x.p; p.b0_bstride = x.bstride(); p.ld0 = C; p.c0 = C;
+        p.cols_mode = COLS_S1; p.H = x.H; p.W = x.W; p.Wp = x.W + 2; p.Hi = x.H; p.Wi = x.W; p.Wpi = p.Wp;
+        p.p0 = p.Wp + 1; p.pn = (x.H - 1) * p.Wp + x.W;
+        p.ntaps = 1; p.cg = C; p.cpt = C / 8; p.nk = C / CG_BK;
+        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = wqkv.rows_pad / 128; p.nbatch = B;
+        p.fold = 1; p.stats0 = x.stats; p.inv_count = 1.0 / ((double)C * N);
+        p.Tb = wqkv.Tb; p.Tg = wqkv.Tg; p.tab_ld = 3 * C; p.bias = nullptr;
+        p.out = a.qkv; p.out_bstride = (long long)N * 3 * C; p.out_ld = 3 * C; p.out_compact = 1; p.nfeat = 3 * C;
+        launch_cgemm(p, 128, EPI_STD, st);
+    }
+    // 2. V^T [B][C][Npad]
+    hipLaunchKernelGGL(transpose_v_kernel, dim3((Npad + 31) / 32, C / 32, B), dim3(256), 0, st,
+                       a.qkv, N, 3 * C, 2 * C, C, Npad, a.Vt);
+    // 3. S[i][j] = q_i . k_j / sqrt(C)   (rows = keys j, cols = queries i)
+    {
+        GemmP p; zero_gemm(p);
+        p.A = a.qkv + C; p.a_bstride = (long long)N * 3 * C; p.a_ld = 3 * C; p.a_rows = N;
+        p.B0 = a.qkv; p.b0_bstride = (long long)N * 3 * C; p.ld0 = 3 * C; p.c0 = C;
+        p.cols_mode = COLS_PLAIN; p.H = 1; p.W = N; p.Wp = N; p.p0 = 0; p.pn = N;
+        p.ntaps = 1; p.cg = C; p.cpt = C / 8; p.nk = C / CG_BK;
+        p.tiles = (N + CG_TP - 1) / CG_TP; p.rowtiles = (N + 127) / 128; p.nbatch = B;
+        p.alpha = 1.0f / sqrtf((float)C);
+        p.out = a.S; p.out_f32 = 1; p.out_bstride = (long long)N * Npad; p.out_ld = Npad; p.nfeat = N;
+        launch_cgemm(p, 128, EPI_STD, st);
+    }
+    // 4. P = softmax_j(S)
+    {
+        const long long rows = (long long)B * N;
+        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.S, a.P, rows, N, Npad);
+    }
+    // 5. O[i][c] = sum_j P[i][j] V[c][j]   (rows = channels, cols = queries, K = Npad)
+    {
+        GemmP p; zero_gemm(p);
+        p.A = a.Vt; p.a_bstride = (long long)C * Npad; p.a_ld = Npad; p.a_rows = C;
+        p.B0 = a.P; p.b0_bstride = (long long)N * Npad; p.ld0 = Npad; p.c0 = Npad;
+        p.cols_mode = COLS_PLAIN; p.H = 1; p.W = N; p.Wp = N; p.p0 = 0; p.pn = N;
+        p.ntaps = 1; p.cg = Npad; p.cpt = Npad / 8; p.nk = Npad / CG_BK;
+        p.tiles = (N + CG_TP - 1) / CG_TP; p.rowtiles = C / 128; p.nbatch = B;
+        p.out = a.O; p.out_bstride = (long long)N * C; p.out_ld = C; p.nfeat = C;
+        launch_cgemm(p, 128, EPI_STD, st);
+    }
+    // 6. y = conv1x1(O) + bias + x
+    {
+        GemmP p; zero_gemm(p);
+        p.A = wout.A; p.a_ld = wout.Kpad; p.a_rows = wout.rows_pad;
+        p.B0 = a.O; p.b0_bstride = (long long)N * C; p.ld0 = C; p.c0 = C; p.in_compact = 1;
+        p.cols_mode = COLS_S1; p.H = x.H; p.W = x.W; p.Wp = x.W + 2; p.Hi = x.H; p.Wi = x.W; p.Wpi = p.Wp;
+        p.p0 = p.Wp + 1; p.pn = (x.H - 1) * p.Wp + x.W;
+        p.ntaps = 1; p.cg = C; p.cpt = C / 8; p.nk = C / CG_BK;
+        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = wout.rows_pad / 128; p.nbatch = B;
+        p.bias = wout.bias;
+        p.res = x.p; p.res_bstride = x.bstride(); p.res_ld = C;
+        p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
+        p.npart = p.tiles * p.rowtiles;
+        require(p.npart <= y.npart, "attention: partial buffer too small");
+        p.partials = y.partials;
+        launch_cgemm(p, 128, EPI_STD, st);
+        y.npart = p.npart; finalize_stats(y, st);
+    }
+    HIPC(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// network description (mirrors DY3h.__init__, model/ucdir.py:219-260)
+// ------------------------------------------------------------------------------------------------
+struct LayerDesc {
+    std::string kind, name;   // stem | block | down | up
+    int level = 0, cin = 0, cout = 0, skip_c = 0; bool attn = false, push_skip = false;
+};
+
+static std::vector<LayerDesc> build_layers(const ucdir_config& c) {
+    std::vector<LayerDesc> L;
+    const int inner = c.inner_channel, nm = c.n_mults;
+    int pre = inner, res = c.image_size, level = 0, idx = 1;
+    std::vector<int> feat{pre};
+    auto in_attn = [&](int r) { for (int i = 0; i < c.n_attn_res; ++i) if (c.attn_res[i] == r) return true; return false; };
+    { LayerDesc d; d.kind = "stem"; d.name = "downs.0"; d.cin = c.in_channel; d.cout = inner; d.push_skip = true; L.push_back(d); }
+    for (int ind = 0; ind < nm; ++ind) {
+        const bool last = ind == nm - 1, ua = in_attn(res);
+        const int cm = inner * c.channel_mults[ind];
+        for (int r = 0; r < c.res_blocks; ++r) {
+            LayerDesc d; d.kind = "block"; d.name = "downs." + std::to_string(idx++); d.level = level;
+            d.cin = pre; d.cout = cm; d.attn = ua; d.push_skip = true; L.push_back(d);
+            feat.push_back(cm); pre = cm;
+        }
+        if (!last) {
+            LayerDesc d; d.kind = "down"; d.name = "downs." + std::to_string(idx++); d.level = level;
+            d.cin = pre; d.cout = pre; d.push_skip = true; L.push_back(d);
+            feat.push_back(pre); res /= 2; ++level;
+        }
+    }
+    { LayerDesc d; d.kind = "block"; d.name = "mid.0"; d.level = level; d.cin = pre; d.cout = pre; d.attn = true; L.push_back(d); }
+    { LayerDesc d; d.kind = "block"; d.name = "mid.1"; d.level = level; d.cin = pre; d.cout = pre; L.push_back(d); }
+    idx = 0;
+    for (int ind = nm - 1; ind >= 0; --ind) {
+        const bool last = ind < 1, ua = in_attn(res);
+        const int cm = inner * c.channel_mults[ind];
+        for (int r = 0; r < c.res_blocks + 1; ++r) {
+            const int sc = feat.back(); feat.pop_back();
+            LayerDesc d; d.kind = "block"; d.name = "ups." + std::to_string(idx++); d.level = level;
+            d.cin = pre + sc; d.cout = cm; d.skip_c = sc; d.attn = ua; L.push_back(d);
+            pre = cm;
+        }
+        if (!last) {
+            LayerDesc d; d.kind = "up"; d.name = "ups." + std::to_string(idx++); d.level = level;
+            d.cin = pre; d.cout = pre; L.push_back(d);
+            res *= 2; --level;
+        }
+    }
+    return L;
+}
+
+struct HostT { std::vector<float> v; std::vector<int64_t> shape; };
+
+struct LayerW {
+    ConvW conv;           // stem (unused: own kernel) / down / up / block conv1
+    ConvW resconv; bool has_res = false;
+    AkgmW sp;
+    ConvW qkv, outp;
+    float* gw = nullptr;  // guide branch weights
+    float* stem_w = nullptr; float* stem_b = nullptr;
+    int block_index = -1;
+};
+
+struct LayerRT {           // per-shape runtime buffers of one layer
+    Act out;               // layer output (after attention if any)
+    Act h1, res, bo;       // block internals: swish(conv1), res_conv(x), block output before attention
+    float* G = nullptr;    // guide branch [B][Hl*Wl][8]
+};
+
+struct ucdir_ctx {
+    ucdir_config cfg{};
+    std::vector<LayerDesc> layers;
+    std::vector<std::string> wnames;
+    std::map<std::string, HostT> host;
+    bool finalized = false;
+    DevPool wpool;                      // packed weights
+    std::vector<LayerW> lw;
+    int nblocks = 0;
+    float *mlp_w1 = nullptr, *mlp_b1 = nullptr, *mlp_w2 = nullptr, *mlp_b2 = nullptr, *tw = nullptr;
+    float *fin_gamma = nullptr, *fin_beta = nullptr, *fin_w = nullptr, *fin_b = nullptr;
+    // shape-dependent state
+    DevPool apool;
+    int B = 0, H = 0, W = 0, Hc = 0, Wc = 0, pad_mode = 1;
+    std::vector<LayerRT> rt;
+    AttnBufs attn;
+    float* attw = nullptr;              // [nblocks][B][8]
+    bool guide_ready = false;
+    double flops = 0;
+};
+
+static std::vector<std::string> expected_names(const ucdir_config& c, const std::vector<LayerDesc>& L) {
+    std::vector<std::string> n{"noise_level_mlp.1.weight", "noise_level_mlp.1.bias", "noise_level_mlp.3.weight",
+                               "noise_level_mlp.3.bias"};
+    for (const auto& d : L) {
+        if (d.kind == "stem") { n.push_back(d.name + ".weight"); n.push_back(d.name + ".bias"); }
+        else if (d.kind == "down" || d.kind == "up") { n.push_back(d.name + ".conv.weight"); n.push_back(d.name + ".conv.bias"); }
+        else {
+            const std::string r = d.name + ".res_block.";
+            for (const char* s : {"noise_func.0.weight", "noise_func.0.bias", "noise_func.2.weight", "noise_func.2.bias",
+                                  "norm1.weight", "norm1.bias", "conv1.weight", "conv1.bias", "norm2.weight", "norm2.bias",
+                                  "conv2.0.weight", "conv2.0.bias", "conv2.2.weight", "conv2.2.bias", "spdyconv.weight",
+                                  "spdyconv.bias"})
+                n.push_back(r + s);
+            if (d.cin != d.cout) { n.push_back(r + "res_conv.weight"); n.push_back(r + "res_conv.bias"); }
+            if (d.attn) for (const char* s : {"norm.weight", "norm.bias", "qkv.weight", "out.weight", "out.bias"})
+                n.push_back(d.name + ".attn." + s);
+        }
+    }
+    for (const char* s : {"final_conv.0.weight", "final_conv.0.bias", "final_conv.3.weight", "final_conv.3.bias"}) n.push_back(s);
+    (void)c;
+    return n;
+}
+
+static const std::vector<float>& W_(ucdir_ctx* c, const std::string& name, size_t expect) {
+    auto it = c->host.find(name);
+    require(it != c->host.end(), "missing weight: " + name);
+    require(it->second.v.size() == expect, "weight " + name + " has wrong size");
+    return it->second.v;
+}
+
+static void finalize_weights(ucdir_ctx* c) {
+    const auto& cfg = c->cfg;
+    const int inner = cfg.inner_channel;
+    c->wpool.release();
+    c->lw.assign(c->layers.size(), LayerW());
+    c->mlp_w1 = c->wpool.upload(W_(c, "noise_level_mlp.1.weight", (size_t)4 * inner * inner));
+    c->mlp_b1 = c->wpool.upload(W_(c, "noise_level_mlp.1.bias", (size_t)4 * inner));
+    c->mlp_w2 = c->wpool.upload(W_(c, "noise_level_mlp.3.weight", (size_t)4 * inner * inner));
+    c->mlp_b2 = c->wpool.upload(W_(c, "noise_level_mlp.3.bias", (size_t)inner));
+    std::vector<float> tw;
+    int nb = 0;
+    for (size_t li = 0; li < c->layers.size(); ++li) {
+        const LayerDesc& d = c->layers[li];
+        LayerW& w = c->lw[li];
+        if (d.kind == "stem") {
+            const auto& sw = W_(c, d.name + ".weight", (size_t)d.cout * d.cin * 9);
+            require(d.cin == 6, "stem expects in_channel == 6 (cat[cond, x_t])");
+            std::vector<float> t((size_t)54 * d.cout);
+            for (int o = 0; o < d.cout; ++o) for (int ci = 0; ci < 6; ++ci) for (int k = 0; k < 9; ++k)
+                t[(size_t)(k * 6 + ci) * d.cout + o] = sw[((size_t)o * 6 + ci) * 9 + k];
+            w.stem_w = c->wpool.upload(t);
+            w.stem_b = c->wpool.upload(W_(c, d.name + ".bias", (size_t)d.cout));
+        } else if (d.kind == "down" || d.kind == "up") {
+            w.conv = upload_conv(c->wpool, W_(c, d.name + ".conv.weight", (size_t)d.cout * d.cin * 9).data(),
+                                 W_(c, d.name + ".conv.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cin, 3);
+        } else {
+            const std::string r = d.name + ".res_block.";
+            w.block_index = nb++;
+            w.conv = upload_conv(c->wpool, W_(c, r + "conv1.weight", (size_t)d.cout * d.cin * 9).data(),
+                                 W_(c, r + "conv1.bias", d.cout).data(), W_(c, r + "norm1.weight", d.cin).data(),
+                                 W_(c, r + "norm1.bias", d.cin).data(), d.cout, d.cin, 3);
+            w.has_res = d.cin != d.cout;
+            if (w.has_res)
+                w.resconv = upload_conv(c->wpool, W_(c, r + "res_conv.weight", (size_t)d.cout * d.cin).data(),
+                                        W_(c, r + "res_conv.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cin, 1);
+            w.sp = upload_akgm(c->wpool, W_(c, r + "spdyconv.weight", (size_t)8 * d.cout * (d.cout / 8) * 9).data(),
+                               W_(c, r + "spdyconv.bias", (size_t)8 * d.cout).data(), W_(c, r + "norm2.weight", d.cout).data(),
+                               W_(c, r + "norm2.bias", d.cout).data(), d.cout);
+            std::vector<float> gw;
+            for (const char* s : {"conv2.0.weight", "conv2.0.bias", "conv2.2.weight", "conv2.2.bias"}) {
+                const auto& v = c->host.at(r + s).v;
+                gw.insert(gw.end(), v.begin(), v.end());
+            }
+            require(gw.size() == 48 + 16 + 576 + 8, "guide branch weights have wrong size");
+            w.gw = c->wpool.upload(gw);
+            for (const char* s : {"noise_func.0.weight", "noise_func.0.bias", "noise_func.2.weight", "noise_func.2.bias"}) {
+                const auto& v = c->host.at(r + s).v;
+                tw.insert(tw.end(), v.begin(), v.end());
+            }
+            if (d.attn) {
+                const std::string a = d.name + ".attn.";
+                w.qkv = upload_conv(c->wpool, W_(c, a + "qkv.weight", (size_t)3 * d.cout * d.cout).data(), nullptr,
+                                    W_(c, a + "norm.weight", d.cout).data(), W_(c, a + "norm.bias", d.cout).data(),
+                                    3 * d.cout, d.cout, 1);
+                w.outp = upload_conv(c->wpool, W_(c, a + "out.weight", (size_t)d.cout * d.cout).data(),
+                                     W_(c, a + "out.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cout, 1);
+            }
+        }
+    }
+    c->nblocks = nb;
+    require(tw.size() == (size_t)nb * (8 * inner + 8 + 64 + 8), "time weights have wrong size");
+    c->tw = c->wpool.upload(tw);
+    const int fc = inner * cfg.channel_mults[0];
+    c->fin_gamma = c->wpool.upload(W_(c, "final_conv.0.weight", fc));
+    c->fin_beta = c->wpool.upload(W_(c, "final_conv.0.bias", fc));
+    {
+        const auto& fw = W_(c, "final_conv.3.weight", (size_t)cfg.out_channel * fc * 9);
+        require(cfg.out_channel <= 4, "final conv supports out_channel <= 4");
+        std::vector<float> t((size_t)9 * fc * 4, 0.f);
+        for (int o = 0; o < cfg.out_channel; ++o) for (int ci = 0; ci < fc; ++ci) for (int k = 0; k < 9; ++k)
+            t[((size_t)k * fc + ci) * 4 + o] = fw[((size_t)o * fc + ci) * 9 + k];
+        c->fin_w = c->wpool.upload(t);
+        c->fin_b = c->wpool.upload(W_(c, "final_conv.3.bias", cfg.out_channel));
+    }
+    c->host.clear();
+    c->finalized = true;
+}
+
+static int level_dim(int d, int level) { return d >> level; }
+
+static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
+    c->apool.release();
+    c->rt.assign(c->layers.size(), LayerRT());
+    c->B = B; c->H = H; c->W = W; c->pad_mode = pad_mode;
+    if (pad_mode) { c->Hc = (H / 32 + 1) * 32; c->Wc = (W / 32 + 1) * 32; require(H >= 33 && W >= 33, "H, W must be >= 33 (reflect pad)"); }
+    else { c->Hc = H; c->Wc = W; }
+    const int nlev = c->cfg.n_mults;
+    require(c->Hc % (1 << (nlev - 1)) == 0 && c->Wc % (1 << (nlev - 1)) == 0, "compute size must be divisible by 2^(levels-1)");
+    int maxN = 0, attC = 0;
+    double fl = 0;
+    int level = 0;
+    for (size_t li = 0; li < c->layers.size(); ++li) {
+        const LayerDesc& d = c->layers[li];
+        LayerRT& r = c->rt[li];
+        if (d.kind == "stem") {
+            r.out = make_act(c->apool, B, c->Hc, c->Wc, d.cout);
+            fl += 2.0 * 9 * d.cin * d.cout * c->Hc * c->Wc;
+        } else if (d.kind == "down") {
+            const int h = level_dim(c->Hc, d.level + 1), w = level_dim(c->Wc, d.level + 1);
+            r.out = make_act(c->apool, B, h, w, d.cout);
+            fl += 2.0 * 9 * d.cin * d.cout * h * w;
+            level = d.level + 1;
+        } else if (d.kind == "up") {
+            const int h = level_dim(c->Hc, d.level - 1), w = level_dim(c->Wc, d.level - 1);
+            r.out = make_act(c->apool, B, h, w, d.cout);
+            fl += 2.0 * 9 * d.cin * d.cout * h * w;
+            level = d.level - 1;
+        } else {
+            const int h = level_dim(c->Hc, d.level), w = level_dim(c->Wc, d.level);
+            r.h1 = make_act(c->apool, B, h, w, d.cout);
+            if (d.cin != d.cout) r.res = make_act(c->apool, B, h, w, d.cout, false);
+            r.out = make_act(c->apool, B, h, w, d.cout);
+            if (d.attn) r.bo = make_act(c->apool, B, h, w, d.cout);
+            r.G = (float*)c->apool.alloc((size_t)B * h * w * 8 * sizeof(float));
+            const double hw = (double)h * w;
+            fl += 2.0 * 9 * d.cin * d.cout * hw + 2.0 * 9 * d.cout * d.cout * hw;
+            if (d.cin != d.cout) fl += 2.0 * d.cin * d.cout * hw;
+            fl += 2.0 * hw * (3 * 16 + 72 * 8);
+            if (d.attn) {
+                if (h * w > maxN) maxN = h * w;
+                attC = d.cout;
+                fl += 2.0 * d.cout * 3 * d.cout * hw + 2.0 * d.cout * d.cout * hw + 4.0 * hw * hw * d.cout;
+            }
+        }
+    }
+    (void)level;
+    fl += 2.0 * 9 * c->cfg.inner_channel * c->cfg.channel_mults[0] * c->cfg.out_channel * c->Hc * c->Wc;
+    c->flops = fl * B;
+    if (maxN > 0) alloc_attn(c->apool, c->attn, B, maxN, attC);
+    c->attw = (float*)c->apool.alloc((size_t)c->nblocks * B * 8 * sizeof(float));
+    c->guide_ready = false;
+}
+
+static void forward(ucdir_ctx* c, const float* cond, const float* xt, const float* level, float* eps, hipStream_t st) {
+    require(c->finalized, "weights not finalized");
+    require(c->guide_ready, "ucdir_prepare_guide must be called before ucdir_unet_forward");
+    const int B = c->B, inner = c->cfg.inner_channel;
+    // 1. noise-level embedding and every block's time weights
+    {
+        const size_t sm = (size_t)(6 * inner + c->nblocks * 8) * sizeof(float);
+        hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), sm, st, level, inner, c->mlp_w1, c->mlp_b1, c->mlp_w2,
+                           c->mlp_b2, c->tw, c->nblocks, c->attw, B);
+        HIPC(hipGetLastError());
+    }
+    std::vector<const Act*> skips;
+    const Act* cur = nullptr;
+    for (size_t li = 0; li < c->layers.size(); ++li) {
+        const LayerDesc& d = c->layers[li];
+        const LayerW& w = c->lw[li];
+        LayerRT& r = c->rt[li];
+        if (d.kind == "stem") {
+            dim3 grid((c->Hc * c->Wc + 255) / 256, d.cout / 64, B);
+            r.out.npart = (int)(grid.x * grid.y);
+            hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, cond, xt, c->H, c->W, c->Hc, c->Wc, d.cout, w.stem_w,
+                               w.stem_b, r.out.p, r.out.partials, r.out.npart);
+            HIPC(hipGetLastError());
+            finalize_stats(r.out, st);
+        } else if (d.kind == "down") {
+            run_conv(w.conv, *cur, nullptr, r.out, COLS_DOWN, 0, nullptr, true, st);
+        } else if (d.kind == "up") {
+            run_conv(w.conv, *cur, nullptr, r.out, COLS_UP, 0, nullptr, true, st);
+        } else {
+            const Act* x0 = cur; const Act* x1 = nullptr;
+            if (d.skip_c) { x1 = skips.back(); skips.pop_back(); require(x1->C == d.skip_c, "skip channel mismatch"); }
+            // h1 = swish(conv1(GN1(cat[x0,x1])))
+            run_conv(w.conv, *x0, x1, r.h1, COLS_S1, 1, nullptr, true, st);
+            const Act* res = x0;
+            if (w.has_res) { run_conv(w.resconv, *x0, x1, r.res, COLS_S1, 0, nullptr, false, st); res = &r.res; }
+            Act& bo = d.attn ? r.bo : r.out;
+            run_akgm(w.sp, r.h1, r.G, c->attw + (size_t)w.block_index * B * 8, *res, bo, st);
+            if (d.attn) run_attention(w.qkv, w.outp, bo, r.out, c->attn, st);
+        }
+        cur = &r.out;
+        if (d.push_skip) skips.push_back(cur);
+    }
+    // final_conv
+    {
+        const int C = cur->C;
+        const size_t sm = (size_t)(2 * C + 9 * C * 4) * sizeof(float);
+        dim3 grid((c->H * c->W + 255) / 256, 1, B);
+        hipLaunchKernelGGL(final_kernel, grid, dim3(256), sm, st, cur->p, c->Hc, c->Wc, C, cur->stats,
+                           1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b,
+                           c->cfg.out_channel, eps, c->H, c->W);
+        HIPC(hipGetLastError());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t ucdir_abi_version(void) { return UCDIR_ABI_VERSION; }
+const char* ucdir_last_error(void) { return g_err.c_str(); }
+
+int32_t ucdir_create(const ucdir_config* cfg, ucdir_ctx** out) {
+    API_BEGIN
+    require(cfg && out, "null argument");
+    require(cfg->n_mults >= 1 && cfg->n_mults <= UCDIR_MAX_MULTS, "bad n_mults");
+    require(cfg->inner_channel % 64 == 0, "inner_channel must be a multiple of 64");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    require(e == hipSuccess && ndev > 0, "no HIP device available (libucdir_hip has no CPU fallback)");
+    HIPC(hipSetDevice(cfg->device));
+    set_kernel_attrs();
+    std::unique_ptr<ucdir_ctx> c(new ucdir_ctx());
+    c->cfg = *cfg;
+    c->layers = build_layers(*cfg);
+    for (const auto& d : c->layers)
+        if (d.kind == "block") require(d.cout == 64 || d.cout % 128 == 0, "block channels must be 64 or a multiple of 128");
+    c->wnames = expected_names(*cfg, c->layers);
+    *out = c.release();
+    API_END
+}
+
+void ucdir_destroy(ucdir_ctx* ctx) { delete ctx; }
+
+int32_t ucdir_num_weights(const ucdir_ctx* ctx) { return ctx ? (int32_t)ctx->wnames.size() : 0; }
+const char* ucdir_weight_name(const ucdir_ctx* ctx, int32_t i) {
+    if (!ctx || i < 0 || i >= (int32_t)ctx->wnames.size()) return nullptr;
+    return ctx->wnames[i].c_str();
+}
+
+int32_t ucdir_load_weight(ucdir_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int32_t ndim) {
+    API_BEGIN
+    require(ctx && name && data_host && shape, "null argument");
+    HostT t; size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.v.assign(data_host, data_host + n);
+    ctx->host[name] = std::move(t);
+    ctx->finalized = false;
+    API_END
+}
+
+int32_t ucdir_finalize_weights(ucdir_ctx* ctx) {
+    API_BEGIN
+    require(ctx, "null ctx");
+    HIPC(hipSetDevice(ctx->cfg.device));
+    for (const auto& n : ctx->wnames) require(ctx->host.count(n) == 1, "missing weight: " + n);
+    finalize_weights(ctx);
+    HIPC(hipDeviceSynchronize());
+    API_END
+}
+
+int32_t ucdir_prepare_guide(ucdir_ctx* ctx, const float* guide, int32_t B, int32_t H, int32_t W, int32_t pad_mode, void* stream) {
+    API_BEGIN
+    require(ctx && guide, "null argument");
+    require(ctx->finalized, "weights not finalized");
+    hipStream_t st = (hipStream_t)stream;
+    if (B != ctx->B || H != ctx->H || W != ctx->W || pad_mode != ctx->pad_mode || ctx->rt.empty()) {
+        HIPC(hipStreamSynchronize(st));
+        plan_shapes(ctx, B, H, W, pad_mode);
+        HIPC(hipDeviceSynchronize());
+    }
+    for (size_t li = 0; li < ctx->layers.size(); ++li) {
+        const LayerDesc& d = ctx->layers[li];
+        if (d.kind != "block") continue;
+        const int k = 1 << d.level;
+        const int hl = ctx->Hc / k, wl = ctx->Wc / k;
+        hipLaunchKernelGGL(guide_branch_kernel, dim3((hl * wl + 255) / 256, 1, B), dim3(256), 0, st, guide, H, W, ctx->Hc,
+                           ctx->Wc, k, ctx->lw[li].gw, ctx->rt[li].G);
+        HIPC(hipGetLastError());
+    }
+    ctx->guide_ready = true;
+    API_END
+}
+
+int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t, const float* noise_level, float* eps, void* stream) {
+    API_BEGIN
+    require(ctx && cond && x_t && noise_level && eps, "null argument");
+    forward(ctx, cond, x_t, noise_level, eps, (hipStream_t)stream);
+    API_END
+}
+
+int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int64_t n, float c_recip, float c_recipm1,
+                           float coef1, float coef2, float sigma, void* stream) {
+    API_BEGIN
+    require(x_t && eps, "null argument");
+    long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, eps,
+                       sigma != 0.f ? noise : nullptr, (long long)n, c_recip, c_recipm1, coef1, coef2, sigma);
+    HIPC(hipGetLastError());
+    API_END
+}
+
+int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst, int64_t dst_elems, void* stream) {
+    API_BEGIN
+    require(ctx && layer && what && dst, "null argument");
+    for (size_t li = 0; li < ctx->layers.size(); ++li) {
+        if (ctx->layers[li].name != layer) continue;
+        const LayerRT& r = ctx->rt[li];
+        const Act* a = &r.out;
+        if (!strcmp(what, "h1")) a = &r.h1;
+        else if (!strcmp(what, "res")) a = &r.res;
+        else if (!strcmp(what, "bo")) a = &r.bo;
+        require(a->p != nullptr, "no such activation");
+        const int64_t n = (int64_t)a->B * a->C * a->H * a->W;
+        require(n == dst_elems, "debug_read: dst has " + std::to_string(dst_elems) + " elements, activation has " + std::to_string(n));
+        hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a->p, dst, a->B, a->C, a->H, a->W);
+        HIPC(hipGetLastError());
+        return 0;
+    }
+    throw std::runtime_error(std::string("unknown layer ") + layer);
+    API_END
+}
+
+int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx) { return ctx ? ctx->apool.bytes + ctx->wpool.bytes : 0; }
+double ucdir_forward_flops(const ucdir_ctx* ctx) { return ctx ? ctx->flops : 0.0; }
+
+// ---- single-operator entry points --------------------------------------------------------------
+static Act act_from_nchw(DevPool& pool, const float* x, int B, int C, int H, int W, hipStream_t st, bool stats) {
+    Act a = make_act(pool, B, H, W, C, true);
+    hipLaunchKernelGGL(nchw_to_act_kernel, dim3(2048), dim3(256), 0, st, x, a.p, B, C, H, W);
+    if (stats) hipLaunchKernelGGL(act_stats_kernel, dim3(B), dim3(256), 0, st, a.p, H, W, C, a.stats);
+    HIPC(hipGetLastError());
+    return a;
+}
+
+int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, int32_t B, int32_t H, int32_t W,
+                      const float* w_host, const float* bias_host, const float* gamma_host, const float* beta_host,
+                      int32_t cout, int32_t ksize, int32_t mode, int32_t silu, const float* residual, float* y,
+                      double* stats_out_host, void* stream) {
+    API_BEGIN
+    set_kernel_attrs();
+    hipStream_t st = (hipStream_t)stream;
+    DevPool pool;
+    Act a0 = act_from_nchw(pool, x0, B, c0, H, W, st, true);
+    Act a1; if (x1) a1 = act_from_nchw(pool, x1, B, c1, H, W, st, true);
+    int Ho = H, Wo = W;
+    if (mode == COLS_DOWN) { Ho = H / 2; Wo = W / 2; } else if (mode == COLS_UP) { Ho = 2 * H; Wo = 2 * W; }
+    Act out = make_act(pool, B, Ho, Wo, cout);
+    Act res; if (residual) res = act_from_nchw(pool, residual, B, cout, Ho, Wo, st, false);
+    ConvW w = upload_conv(pool, w_host, bias_host, gamma_host, beta_host, cout, c0 + (x1 ? c1 : 0), ksize);
+    run_conv(w, a0, x1 ? &a1 : nullptr, out, mode, silu, residual ? &res : nullptr, true, st);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, cout, Ho, Wo);
+    HIPC(hipGetLastError());
+    if (stats_out_host) HIPC(hipMemcpyAsync(stats_out_host, out.stats, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    API_END
+}
+
+int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_t B, int32_t C, int32_t H, int32_t W,
+                      const float* wsp_host, const float* bsp_host, const float* gamma_host, const float* beta_host,
+                      float* y, void* stream) {
+    API_BEGIN
+    set_kernel_attrs();
+    hipStream_t st = (hipStream_t)stream;
+    DevPool pool;
+    Act ah = act_from_nchw(pool, h, B, C, H, W, st, true);
+    Act ar = act_from_nchw(pool, res, B, C, H, W, st, false);
+    Act out = make_act(pool, B, H, W, C);
+    float* G = (float*)pool.alloc((size_t)B * H * W * 8 * 4);
+    hipLaunchKernelGGL(nchw8_to_compact_kernel, dim3(1024), dim3(256), 0, st, att, G, B, H, W);
+    std::vector<float> ones((size_t)B * 8, 1.f);
+    float* attw = pool.upload(ones);
+    AkgmW w = upload_akgm(pool, wsp_host, bsp_host, gamma_host, beta_host, C);
+    run_akgm(w, ah, G, attw, ar, out, st);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));
+    API_END
+}
+
+int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, const float* gamma_host,
+                           const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
+                           float* y, void* stream) {
+    API_BEGIN
+    set_kernel_attrs();
+    hipStream_t st = (hipStream_t)stream;
+    DevPool pool;
+    Act ax = act_from_nchw(pool, x, B, C, H, W, st, true);
+    Act out = make_act(pool, B, H, W, C);
+    AttnBufs ab; alloc_attn(pool, ab, B, H * W, C);
+    ConvW wq = upload_conv(pool, wqkv_host, nullptr, gamma_host, beta_host, 3 * C, C, 1);
+    ConvW wo = upload_conv(pool, wout_host, bout_host, nullptr, nullptr, C, C, 1);
+    run_attention(wq, wo, ax, out, ab, st);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,365 @@
+// Small HBM-bound kernels around the GEMM core (gfx950).
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics: reduce per-workgroup partial sums (written by producer epilogues, fp32)
+// into per-sample (sum, sumsq) in double.  Deterministic (fixed order), one block per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ void stats_finalize_kernel(const float* __restrict__ partials, int npart, double* __restrict__ stats) {
+    const int b = blockIdx.x;
+    const float* pp = partials + (long long)b * npart * 2;
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < npart; i += blockDim.x) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { stats[b * 2] = sh[0][0]; stats[b * 2 + 1] = sh[1][0]; }
+}
+
+// direct statistics of an activation tensor (tests / inputs produced outside the GEMM core)
+__global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int C, double* __restrict__ stats) {
+    const int b = blockIdx.x;
+    const int Wp = W + 2;
+    const long long bs = (long long)(H + 2) * Wp * C;
+    const int c8 = C / 8;
+    double s1 = 0, s2 = 0;
+    for (long long i = threadIdx.x; i < (long long)H * W * c8; i += blockDim.x) {
+        int c = (int)(i % c8);
+        long long pix = i / c8;
+        int y = (int)(pix / W), xx = (int)(pix % W);
+        const uint4 v = *reinterpret_cast<const uint4*>(x + b * bs + ((long long)(y + 1) * Wp + xx + 1) * C + c * 8);
+        const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float f = bf2f(h[k]); s1 += f; s2 += (double)f * f; }
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { stats[b * 2] = sh[0][0]; stats[b * 2 + 1] = sh[1][0]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout converters (ABI boundary, tests, debug taps)
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_act_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int H, int W) {
+    long long n = (long long)B * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C); long long t = i / C;
+        int x = (int)(t % W); t /= W;
+        int y = (int)(t % H); int b = (int)(t / H);
+        float v = src[(((long long)b * C + c) * H + y) * W + x];
+        dst[(((long long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = f2bf(v);
+    }
+}
+__global__ void act_to_nchw_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W) {
+    long long n = (long long)B * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(i % W); long long t = i / W;
+        int y = (int)(t % H); t /= H;
+        int c = (int)(t % C); int b = (int)(t / C);
+        dst[i] = bf2f(src[(((long long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c]);
+    }
+}
+// (B,8,H,W) fp32 NCHW -> compact [B][H*W][8] fp32 (AKGM modulation, tests)
+__global__ void nchw8_to_compact_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W) {
+    long long n = (long long)B * H * W * 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int s = (int)(i % 8); long long t = i / 8;
+        long long pix = t % ((long long)H * W); int b = (int)(t / ((long long)H * W));
+        dst[i] = src[((long long)b * 8 + s) * H * W + pix];
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * (n - 1) - i; }
+
+// ------------------------------------------------------------------------------------------------
+// stem: conv3x3(cat[cond, x_t]) 6 -> C0, reading the reference's NCHW fp32 tensors directly
+// (with DY3h.forward's bottom/right reflect pad, model/ucdir.py:303-306) and writing the
+// zero-bordered NHWC bf16 activation + GroupNorm partial sums.  K = 54: VALU, not MFMA.
+// grid (ceil(Hc*Wc/256), C0/64, B), block 256; w: [54][C0] fp32 (k = (ky*3+kx)*6 + ci)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cond, const float* __restrict__ xt,
+                                                   int H, int W, int Hc, int Wc, int C0,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   bf16_t* __restrict__ out, float* __restrict__ partials, int npart) {
+    __shared__ __attribute__((aligned(16))) float ws[54 * 64];
+    __shared__ float red[8];
+    const int cb = blockIdx.y * 64;
+    const int b = blockIdx.z;
+    for (int i = threadIdx.x; i < 54 * 64; i += 256) ws[i] = w[(i / 64) * C0 + cb + (i % 64)];
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (pix < Hc * Wc) {
+        const int y = pix / Wc, x = pix % Wc;
+        float acc[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc[c] = bias[cb + c];
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if (yy < 0 || yy >= Hc) continue;
+            const int ys = reflect_idx(yy, H);
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x + kx - 1;
+                if (xx < 0 || xx >= Wc) continue;
+                const int xs = reflect_idx(xx, W);
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) {
+                    const float* src = ci < 3 ? cond : xt;
+                    const float v = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
+                    const float* wr = ws + ((ky * 3 + kx) * 6 + ci) * 64;
+#pragma unroll
+                    for (int c = 0; c < 64; c += 4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
+                        acc[c] += v * w4.x; acc[c + 1] += v * w4.y; acc[c + 2] += v * w4.z; acc[c + 3] += v * w4.w;
+                    }
+                }
+            }
+        }
+        bf16_t* op = out + (((long long)b * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C0 + cb;
+#pragma unroll
+        for (int c = 0; c < 64; c += 8) {
+            uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { oh[k] = f2bf(acc[c + k]); s1 += acc[c + k]; s2 += acc[c + k] * acc[c + k]; }
+            *reinterpret_cast<uint4*>(op + c) = ov;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* pp = partials + ((long long)b * npart + (long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
+        pp[0] = red[0] + red[2] + red[4] + red[6];
+        pp[1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// final_conv: GroupNorm(1) -> Swish -> conv3x3 C -> cout (<= 4), output NCHW fp32 cropped to
+// H x W (model/ucdir.py:266-268, :307).  N = 3 output channels: VALU.
+// grid (ceil(H*W/256), 1, B); w: [9][C][4] fp32 (zero padded), gamma/beta [C]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_kernel(const bf16_t* __restrict__ x, int Hc, int Wc, int C,
+                                                    const double* __restrict__ stats, double inv_count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ w, const float* __restrict__ bias, int cout,
+                                                    float* __restrict__ out, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* sa = fsm;               // [C] scale
+    float* sb = fsm + C;           // [C] shift
+    float* sw = fsm + 2 * C;       // [9][C][4]
+    const int b = blockIdx.z;
+    {
+        double m = stats[b * 2] * inv_count;
+        double var = stats[b * 2 + 1] * inv_count - m * m;
+        if (var < 0) var = 0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + 1e-5));
+        for (int c = threadIdx.x; c < C; c += 256) { sa[c] = rstd * gamma[c]; sb[c] = beta[c] - mean * rstd * gamma[c]; }
+        for (int i = threadIdx.x; i < 9 * C * 4; i += 256) sw[i] = w[i];
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int y = pix / W, xq = pix % W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long bs = (long long)(Hc + 2) * (Wc + 2) * C;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky;           // padded coords: valid rows are 1..Hc
+        if (yy < 1 || yy > Hc) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = xq + kx;
+            if (xx < 1 || xx > Wc) continue;
+            const bf16_t* px = x + b * bs + ((long long)yy * (Wc + 2) + xx) * C;
+            const float* wt = sw + (ky * 3 + kx) * C * 4;
+            for (int c = 0; c < C; c += 8) {
+                const uint4 v = *reinterpret_cast<const uint4*>(px + c);
+                const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float f = bf2f(h[k]) * sa[c + k] + sb[c + k];
+                    f = f / (1.0f + __expf(-f));
+                    const float4 w4 = *reinterpret_cast<const float4*>(wt + (c + k) * 4);
+                    acc[0] += f * w4.x; acc[1] += f * w4.y; acc[2] += f * w4.z; acc[3] += f * w4.w;
+                }
+            }
+        }
+    }
+    for (int co = 0; co < cout; ++co)
+        out[(((long long)b * cout + co) * H + y) * W + xq] = acc[co] + bias[co];
+}
+
+// ------------------------------------------------------------------------------------------------
+// noise-level embedding + every block's time weights (model/ucdir.py:24-29,212-214,106,125)
+// one block per sample.  tw layout per block layer: [8][inner] W0, [8] b0, [8][8] W2, [8] b2
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_mlp_kernel(const float* __restrict__ level, int inner,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ tw, int nblocks,
+                                                       float* __restrict__ attw /*[nblocks][B][8]*/, int B) {
+    extern __shared__ float tsm[];
+    float* enc = tsm;                 // [inner]
+    float* h1 = tsm + inner;          // [4*inner]
+    float* temb = h1 + 4 * inner;     // [inner]
+    float* hid = temb + inner;        // [nblocks][8]
+    const int b = blockIdx.x;
+    const float lv = level[b];
+    const int half = inner / 2;
+    for (int k = threadIdx.x; k < half; k += 256) {
+        const float step = (float)k / (float)half;
+        const float e = lv * expf(-9.210340371976184f * step);
+        enc[k] = sinf(e); enc[k + half] = cosf(e);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * inner; o += 256) {
+        float a = b1[o];
+        for (int k = 0; k < inner; ++k) a += w1[o * inner + k] * enc[k];
+        h1[o] = a / (1.0f + expf(-a));
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < inner; o += 256) {
+        float a = b2[o];
+        for (int k = 0; k < 4 * inner; ++k) a += w2[o * 4 * inner + k] * h1[k];
+        temb[o] = a;
+    }
+    __syncthreads();
+    const int per = 8 * inner + 8 + 64 + 8;
+    for (int i = threadIdx.x; i < nblocks * 8; i += 256) {
+        const int l = i / 8, o = i % 8;
+        const float* W0 = tw + (long long)l * per;
+        float a = W0[8 * inner + o];
+        for (int k = 0; k < inner; ++k) a += W0[o * inner + k] * temb[k];
+        hid[i] = a / (1.0f + expf(-a));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblocks * 8; i += 256) {
+        const int l = i / 8, o = i % 8;
+        const float* W2 = tw + (long long)l * per + 8 * inner + 8;
+        float a = W2[64 + o];
+        for (int k = 0; k < 8; ++k) a += W2[o * 8 + k] * hid[l * 8 + k];
+        attw[((long long)l * B + b) * 8 + o] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// guide branch of one block (model/ucdir.py:133-135 without attw): bilinear 1/k resample of the
+// (reflect padded) guide = mean of the centre 2x2 of each k x k cell, conv1x1 3->16, SimpleGate,
+// conv3x3 8->8.  Independent of t and x_t -> evaluated once per image.  Output compact
+// [B][Hl*Wl][8] fp32.  gw: [16][3] W0, [16] b0, [8][8][3][3] W2, [8] b2
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void guide_branch_kernel(const float* __restrict__ guide, int H, int W, int Hc, int Wc,
+                                                           int k, const float* __restrict__ gw, float* __restrict__ G) {
+    __shared__ float sw[16 * 3 + 16 + 576 + 8];
+    for (int i = threadIdx.x; i < 16 * 3 + 16 + 576 + 8; i += 256) sw[i] = gw[i];
+    __syncthreads();
+    const float* W0 = sw; const float* b0 = sw + 48; const float* W2 = sw + 64; const float* b2 = sw + 64 + 576;
+    const int Hl = Hc / k, Wl = Wc / k;
+    const int b = blockIdx.z;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hl * Wl) return;
+    const int y = pix / Wl, x = pix % Wl;
+    float out[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) out[o] = b2[o];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= Hl) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1;
+            if (xx < 0 || xx >= Wl) continue;
+            float g3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* gp = guide + ((long long)b * 3 + c) * H * W;
+                if (k == 1) {
+                    g3[c] = gp[(long long)reflect_idx(yy, H) * W + reflect_idx(xx, W)];
+                } else {
+                    const int y0 = k * yy + k / 2 - 1, x0 = k * xx + k / 2 - 1;
+                    const int ya = reflect_idx(y0, H), yb = reflect_idx(y0 + 1, H);
+                    const int xa = reflect_idx(x0, W), xb = reflect_idx(x0 + 1, W);
+                    // bilinear with lambda = 0.5 in both directions (ATen order: rows then columns)
+                    const float top = 0.5f * gp[(long long)ya * W + xa] + 0.5f * gp[(long long)ya * W + xb];
+                    const float bot = 0.5f * gp[(long long)yb * W + xa] + 0.5f * gp[(long long)yb * W + xb];
+                    g3[c] = 0.5f * top + 0.5f * bot;
+                }
+            }
+            float v[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) v[o] = b0[o] + W0[o * 3] * g3[0] + W0[o * 3 + 1] * g3[1] + W0[o * 3 + 2] * g3[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = v[i] * v[i + 8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) out[o] += W2[((o * 8 + i) * 3 + ky) * 3 + kx] * a;
+            }
+        }
+    }
+    float* gp = G + ((long long)b * Hl * Wl + pix) * 8;
+    *reinterpret_cast<float4*>(gp) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4*>(gp + 4) = make_float4(out[4], out[5], out[6], out[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax: S fp32 [B][N][Npad] -> P bf16 [B][N][Npad] (columns >= N written as 0).
+// One wave per row, three streaming passes (rows are L2 resident).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                      long long rows, int N, int Npad) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* s = S + row * Npad;
+    bf16_t* pr = P + row * Npad;
+    float m = -3.0e38f;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, s[j]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) sum += expf(s[j] - m);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Npad; j += 64) pr[j] = j < N ? f2bf(expf(s[j] - m) * inv) : (bf16_t)0;
+}
+
+// V^T: QKV compact [B][N][ld] (v at channel offset voff) -> [B][C][Npad] bf16
+__global__ void transpose_v_kernel(const bf16_t* __restrict__ qkv, int N, int ld, int voff, int C, int Npad,
+                                   bf16_t* __restrict__ vt) {
+    __shared__ bf16_t tile[32][33];
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r;
+        tile[r][tx] = n < N ? qkv[((long long)b * N + n) * ld + voff + c0 + tx] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + tx;
+        if (n < Npad) vt[((long long)b * C + c0 + r) * Npad + n] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ancestral sampler update (model/diffusion.py:150-158,171-183), in place
+// ------------------------------------------------------------------------------------------------
+__global__ void sampler_step_kernel(float* __restrict__ xt, const float* __restrict__ eps, const float* __restrict__ noise,
+                                    long long n, float c_recip, float c_recipm1, float coef1, float coef2, float sigma) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = xt[i];
+        float x0 = c_recip * x - c_recipm1 * eps[i];
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float r = coef1 * x0 + coef2 * x;
+        if (noise) r += noise[i] * sigma;
+        xt[i] = r;
+    }
+}

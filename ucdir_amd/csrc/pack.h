@@ -1,0 +1,120 @@
+// Host-side weight packing for the MFMA kernels (pure C++, no device code).
+//
+// * dense conv (3x3 / 1x1): A[o][k], k = tap*Cin + c (tap = ky*3+kx), bf16, optional fold of
+//   the preceding GroupNorm's gamma into the weights;  Tb/Tg border-class tables for the fold
+//   (see cgemm.hip.h header).
+// * spdyconv (grouped, groups = 8, reference model/ucdir.py:116,136-137): per group a
+//   [C][Kpad] matrix whose rows are permuted so that, in the 32x32 MFMA accumulator layout, one
+//   lane holds all 8 kernel sets of a feature (row rho of a 32-row tile <-> feature
+//   4*t + 2*((rho>>4)&1) + ((rho>>2)&1), set (rho&3) + 4*((rho>>3)&1)).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+struct PackedConv {
+    std::vector<bf16_t> A;        // [rows_pad][Kpad]
+    std::vector<float> bias;      // [cout] (zeros if none)
+    std::vector<float> Tb, Tg;    // [ncls][cout]
+    int rows_pad = 0, Kpad = 0, ntaps = 0, cin = 0, cout = 0, ncls = 0;
+};
+
+static inline bool tap_valid(int cls, int tap) {
+    const int cy = cls / 3, cx = cls % 3, ky = tap / 3, kx = tap % 3;
+    if (cy == 0 && ky == 0) return false;
+    if (cy == 2 && ky == 2) return false;
+    if (cx == 0 && kx == 0) return false;
+    if (cx == 2 && kx == 2) return false;
+    return true;
+}
+
+// w: [cout][cin][ks][ks] fp32 (reference Conv2d layout)
+static inline PackedConv pack_conv(const float* w, const float* bias, const float* gamma, const float* beta,
+                                   int cout, int cin, int ks, int TM) {
+    PackedConv P;
+    P.ntaps = ks * ks; P.cin = cin; P.cout = cout;
+    P.Kpad = ((P.ntaps * cin + 63) / 64) * 64;
+    P.rows_pad = ((cout + TM - 1) / TM) * TM;
+    P.A.assign((size_t)P.rows_pad * P.Kpad, 0);
+    P.bias.assign(cout, 0.f);
+    if (bias) for (int o = 0; o < cout; ++o) P.bias[o] = bias[o];
+    P.ncls = (ks == 3) ? 9 : 1;
+    const bool fold = gamma != nullptr;
+    std::vector<double> wb((size_t)P.ntaps * cout, 0.0), wg((size_t)P.ntaps * cout, 0.0);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < P.ntaps; ++t) {
+                const float wv = w[((size_t)o * cin + c) * P.ntaps + t];
+                const float ws = fold ? wv * gamma[c] : wv;
+                const bf16_t q = f2bf(ws);
+                P.A[(size_t)o * P.Kpad + (size_t)t * cin + c] = q;
+                if (fold) {
+                    wb[(size_t)t * cout + o] += (double)wv * beta[c];
+                    wg[(size_t)t * cout + o] += (double)bf2f(q);
+                }
+            }
+    if (fold) {
+        P.Tb.assign((size_t)P.ncls * cout, 0.f);
+        P.Tg.assign((size_t)P.ncls * cout, 0.f);
+        for (int cls = 0; cls < P.ncls; ++cls)
+            for (int o = 0; o < cout; ++o) {
+                double sb = 0, sg = 0;
+                for (int t = 0; t < P.ntaps; ++t) {
+                    const int t9 = (P.ntaps == 9) ? t : 4;
+                    if (P.ncls == 9 && !tap_valid(cls, t9)) continue;
+                    sb += wb[(size_t)t * cout + o]; sg += wg[(size_t)t * cout + o];
+                }
+                P.Tb[(size_t)cls * cout + o] = (float)sb;
+                P.Tg[(size_t)cls * cout + o] = (float)sg;
+            }
+    }
+    return P;
+}
+
+struct PackedAkgm {
+    std::vector<bf16_t> A;        // [8 groups][C rows][Kpad]
+    std::vector<float> bias;      // [8C] original order
+    std::vector<float> Tb, Tg;    // [9][8C] original order
+    int C = 0, cg = 0, Kpad = 0;
+};
+
+// wsp: [8C][C/8][3][3], bsp: [8C], gamma/beta: [C] (norm2)
+static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
+    PackedAkgm P;
+    P.C = C; P.cg = C / 8;
+    const int cg = P.cg;
+    P.Kpad = ((9 * cg + 63) / 64) * 64;
+    P.A.assign((size_t)8 * C * P.Kpad, 0);
+    P.bias.assign((size_t)8 * C, 0.f);
+    P.Tb.assign((size_t)9 * 8 * C, 0.f);
+    P.Tg.assign((size_t)9 * 8 * C, 0.f);
+    for (int o = 0; o < 8 * C; ++o) P.bias[o] = bsp[o];
+    for (int g = 0; g < 8; ++g)
+        for (int pr = 0; pr < C; ++pr) {
+            const int t32 = pr / 32, rho = pr % 32;
+            const int floc = 4 * t32 + ((rho >> 4) & 1) * 2 + ((rho >> 2) & 1);
+            const int s = (rho & 3) + 4 * ((rho >> 3) & 1);
+            const int o = g * C + 8 * floc + s;
+            bf16_t* row = &P.A[((size_t)g * C + pr) * P.Kpad];
+            double wb[9] = {0}, wg[9] = {0};
+            for (int ci = 0; ci < cg; ++ci) {
+                const int cglob = g * cg + ci;
+                for (int t = 0; t < 9; ++t) {
+                    const float wv = wsp[((size_t)o * cg + ci) * 9 + t];
+                    const bf16_t q = f2bf(wv * gamma[cglob]);
+                    row[(size_t)t * cg + ci] = q;
+                    wb[t] += (double)wv * beta[cglob];
+                    wg[t] += (double)bf2f(q);
+                }
+            }
+            for (int cls = 0; cls < 9; ++cls) {
+                double sb = 0, sg = 0;
+                for (int t = 0; t < 9; ++t) if (tap_valid(cls, t)) { sb += wb[t]; sg += wg[t]; }
+                P.Tb[(size_t)cls * 8 * C + o] = (float)sb;
+                P.Tg[(size_t)cls * 8 * C + o] = (float)sg;
+            }
+        }
+    return P;
+}

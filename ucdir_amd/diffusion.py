@@ -1,0 +1,177 @@
+"""Diffusion process for the sampling path (reference: model/diffusion.py).
+
+``GaussianDiffusion`` / ``ResiGaussianGuideDY`` keep the reference's public surface used by
+``DDPM`` and ``sr.py`` (set_new_noise_schedule, super_resolution, p_sample_loop, p_sample, sample,
+set_loss, registered schedule buffers, ``denoise_fn`` / ``predictor`` / ``pre_initx`` attributes)
+so that ``define_G`` is a drop-in.  Training (``p_losses`` / ``forward``) is outside the scope of
+this build and raises.
+
+Differences from the reference, all result-preserving:
+  * the noise level and the five per-step coefficients are read from host tables (float64 ->
+    float32 exactly like ``to_torch``) instead of indexing device buffers + a tiny H2D copy each step
+    (model/diffusion.py:162-163);
+  * the point-wise update runs as one fused HIP kernel (``ucdir_sampler_step``);
+  * ``cat([cond, x_t])`` is not materialised;
+  * batches: the reference's ``ret_img[-1]`` is only correct for B = 1; here a
+    batch is B independent restorations and the non-``continous`` result is (B,3,H,W).
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ucdir import UNetSeeInDark, sampler_step_
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """Beta tables (model/diffusion.py:23-54)."""
+    if schedule == "quad":
+        return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    if schedule == "linear":
+        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+    if schedule in ("warmup10", "warmup50"):
+        betas = linear_end * np.ones(n_timestep, dtype=np.float64)
+        n = int(n_timestep * (0.1 if schedule == "warmup10" else 0.5))
+        betas[:n] = np.linspace(linear_start, linear_end, n, dtype=np.float64)
+        return betas
+    if schedule == "const":
+        return linear_end * np.ones(n_timestep, dtype=np.float64)
+    if schedule == "jsd":
+        return 1.0 / np.linspace(n_timestep, 1, n_timestep, dtype=np.float64)
+    if schedule == "cosine":
+        ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
+        al = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
+        al = al / al[0]
+        return np.minimum(1 - al[1:] / al[:-1], 0.999)
+    raise NotImplementedError(schedule)
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoise_fn, image_size, channels=3, loss_type="l1", conditional=True, schedule_opt=None):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.loss_type = loss_type
+        self.conditional = conditional
+        self.noise_source = None     # optional callable(shape, device, k) -> tensor, for injected noise
+
+    def set_loss(self, device):
+        if self.loss_type == "l1":
+            self.loss_func = nn.L1Loss(reduction="sum").to(device)
+        elif self.loss_type == "l2":
+            self.loss_func = nn.MSELoss(reduction="sum").to(device)
+        else:
+            raise NotImplementedError()
+
+    def set_new_noise_schedule(self, schedule_opt, device):
+        """model/diffusion.py:101-148: same twelve fp32 buffers + float64 sqrt_alphas_cumprod_prev."""
+        to_torch = partial(torch.tensor, dtype=torch.float32, device=device)
+        betas = make_beta_schedule(schedule=schedule_opt["schedule"], n_timestep=schedule_opt["n_timestep"],
+                                   linear_start=schedule_opt["linear_start"], linear_end=schedule_opt["linear_end"])
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.sqrt_alphas_cumprod_prev = np.sqrt(np.append(1.0, ac))
+        self.num_timesteps = int(betas.shape[0])
+        pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+        tables = {
+            "betas": betas, "alphas_cumprod": ac, "alphas_cumprod_prev": ac_prev,
+            "sqrt_alphas_cumprod": np.sqrt(ac), "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+            "log_one_minus_alphas_cumprod": np.log(1.0 - ac),
+            "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / (ac + 1e-10)),
+            "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / (ac + 1e-10) - 1),
+            "posterior_variance": pv,
+            "posterior_log_variance_clipped": np.log(np.maximum(pv, 1e-20)),
+            "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+            "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+        }
+        self._host_tables = {k: np.asarray(v, dtype=np.float32) for k, v in tables.items()}
+        for k, v in tables.items():
+            self.register_buffer(k, to_torch(v))
+
+    # ---- one ancestral step -----------------------------------------------------------------------
+    def step_coefficients(self, t):
+        """(noise_level, c_recip, c_recipm1, coef1, coef2, sigma) of step t as the reference computes them."""
+        T = self._host_tables
+        level = np.float32(self.sqrt_alphas_cumprod_prev[t + 1])          # FloatTensor([...]) rounding
+        sigma = np.exp(np.float32(0.5) * T["posterior_log_variance_clipped"][t]).astype(np.float32) if t > 0 else 0.0
+        return (float(level), float(T["sqrt_recip_alphas_cumprod"][t]), float(T["sqrt_recipm1_alphas_cumprod"][t]),
+                float(T["posterior_mean_coef1"][t]), float(T["posterior_mean_coef2"][t]), float(sigma))
+
+    def _noise(self, like, k):
+        if self.noise_source is not None:
+            return self.noise_source(like.shape, like.device, k)
+        return torch.randn_like(like)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=True, condition_x=None, kwargs={}, _k=None):
+        """model/diffusion.py:178-183 (clip_denoised is always True on the sampling path)."""
+        level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(t)
+        B = x.shape[0]
+        lvl = torch.full((B, 1), level, dtype=torch.float32, device=x.device)
+        guide = kwargs.get("guide")
+        if condition_x is not None:
+            eps = self.denoise_fn.forward_split(condition_x, x, lvl, guide) if self._small(x) else \
+                self.denoise_fn(torch.cat([condition_x, x], dim=1), lvl, guide)
+        else:
+            raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
+        noise = self._noise(x, _k) if t > 0 else None
+        out = x.clone()
+        return sampler_step_(out, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
+
+    def _small(self, x):
+        return x.shape[-1] * x.shape[-2] <= self.denoise_fn.patch_threshold
+
+    @torch.no_grad()
+    def p_sample_loop(self, x_in, continous=False, kwargs={}):
+        """model/diffusion.py:185-211, conditional branch."""
+        if not self.conditional:
+            raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
+        x = x_in
+        sample_inter = 1 | (self.num_timesteps // 10)
+        img = self._noise(x, 0)
+        ret = [x]
+        k = 1
+        for i in reversed(range(self.num_timesteps)):
+            img = self.p_sample(img, i, condition_x=x, kwargs=kwargs, _k=k)
+            if i > 0:
+                k += 1
+            if i % sample_inter == 0:
+                ret.append(img)
+        if continous:
+            return torch.cat(ret, dim=0)
+        return ret[-1]
+
+    @torch.no_grad()
+    def sample(self, batch_size=1, continous=False):
+        raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
+
+    @torch.no_grad()
+    def super_resolution(self, x_in, continous=False):
+        return self.p_sample_loop(x_in, continous)
+
+    def p_losses(self, x_in, noise=None):
+        raise NotImplementedError("training is outside the scope of the MI355X sampling build")
+
+    def forward(self, x, *args, **kwargs):
+        return self.p_losses(x, *args, **kwargs)
+
+
+class ResiGaussianGuideDY(GaussianDiffusion):
+    """model/diffusion.py:436-478: predictor output is both guide and residual base."""
+
+    def __init__(self, denoise_fn, image_size, channels=3, loss_type="l1", conditional=True, schedule_opt=None):
+        super().__init__(denoise_fn, image_size, channels, loss_type, conditional, schedule_opt)
+        self.predictor = UNetSeeInDark()
+
+    @torch.no_grad()
+    def super_resolution(self, x_in, continous=False):
+        initx = self.predictor(x_in)
+        self.pre_initx = initx
+        out = self.p_sample_loop(x_in, continous, kwargs={"guide": initx})
+        if continous and out.shape[0] != initx.shape[0]:
+            reps = out.shape[0] // initx.shape[0]
+            return out + initx.repeat(reps, 1, 1, 1)
+        return out + initx

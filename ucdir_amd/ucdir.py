@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's ``model/ucdir.py`` for the sampling path.
+
+``DY3h`` keeps the reference's constructor arguments, parameter names/shapes (so reference
+checkpoints load with ``load_state_dict``) and call signature
+``denoise_fn(x (B,6,H,W), noise_level (B,1), guide=(B,3,H,W)) -> (B,3,H,W)``
+(reference: model/ucdir.py:204-307), but it has no PyTorch forward: every call goes to the HIP
+engine behind include/ucdir_hip.h.  On a machine without the library or without a GPU it raises.
+
+``UNetSeeInDark`` (the one-shot predictor, model/ucdir.py:310-416) currently runs on stock ATen
+GPU ops; it is 0.13 % of a 50-step restoration (f-rank 1).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as _lib
+from .patch import patch_forward_guide
+from .spec import UNetConfig, predictor_param_shapes, unet_param_shapes
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], param)
+
+
+def _default_init(name, shape):
+    """nn.Conv2d / nn.Linear / nn.GroupNorm default initialisers."""
+    leaf = name.rsplit(".", 1)[-1]
+    if "norm" in name or name.startswith("final_conv.0"):
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else None
+    t = torch.empty(shape)
+    if leaf == "weight":
+        nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+    else:
+        t.zero_()            # bias bound needs the weight's fan-in; filled in by the caller
+    return t
+
+
+class DY3h(nn.Module):
+    """Conditional UNet denoiser; same signature as the reference's ``DY3h`` (model/ucdir.py:204-207)."""
+
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=1, channel_mults=(1, 2, 4, 8, 8),
+                 attn_res=(8,), res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=128,
+                 resname="ResnetBlockDY3h"):
+        super().__init__()
+        if not with_noise_level_emb or resname != "ResnetBlockDY3h":
+            raise NotImplementedError("only the DY3h configuration of config/sid.yaml is implemented")
+        self.cfg = UNetConfig(in_channel=in_channel, out_channel=out_channel, inner_channel=inner_channel,
+                              norm_groups=norm_groups, channel_mults=tuple(channel_mults), attn_res=tuple(attn_res),
+                              res_blocks=res_blocks, dropout=dropout, image_size=image_size)
+        shapes = unet_param_shapes(self.cfg)
+        self._pnames = list(shapes)
+        for name, shape in shapes.items():
+            _attach(self, name, nn.Parameter(_default_init(name, shape)))
+        for name, shape in shapes.items():      # bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch
+            if name.endswith(".bias") and "norm" not in name and not name.startswith("final_conv.0"):
+                w = dict(self.named_parameters())[name[:-5] + ".weight"]
+                bound = 1.0 / math.sqrt(max(int(np.prod(w.shape[1:])), 1))
+                nn.init.uniform_(dict(self.named_parameters())[name], -bound, bound)
+        self.patch_threshold = 1024 * 1024   # model/ucdir.py:298
+        self.patch_skip, self.patch_padding = 1024, 64
+        self._h = None
+        self._wkey = None
+        self._gkey = None
+
+    # ---- engine plumbing -------------------------------------------------------------------------
+    def _device_index(self):
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise _lib.UcdirError("DY3h runs only on an MI355X (move the module to 'cuda'); there is no CPU path")
+        return p.device.index if p.device.index is not None else torch.cuda.current_device()
+
+    def _handle(self):
+        L = _lib.load()
+        if self._h is None:
+            c = _lib.UcdirConfig()
+            cfg = self.cfg
+            c.in_channel, c.out_channel, c.inner_channel = cfg.in_channel, cfg.out_channel, cfg.inner_channel
+            c.n_mults = len(cfg.channel_mults)
+            for i, v in enumerate(cfg.channel_mults):
+                c.channel_mults[i] = v
+            c.n_attn_res = len(cfg.attn_res)
+            for i, v in enumerate(cfg.attn_res):
+                c.attn_res[i] = v
+            c.res_blocks, c.image_size, c.device = cfg.res_blocks, cfg.image_size, self._device_index()
+            h = ctypes.c_void_p()
+            _lib.check(L.ucdir_create(ctypes.byref(c), ctypes.byref(h)))
+            self._h = h
+        return self._h
+
+    def _sync_weights(self):
+        """(Re)pack weights into the engine when parameters changed (load_state_dict, .to, training step)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key == self._wkey:
+            return
+        L = _lib.load()
+        h = self._handle()
+        for name, p in self.named_parameters():
+            a = np.ascontiguousarray(p.detach().float().cpu().numpy())
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            _lib.check(L.ucdir_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
+        _lib.check(L.ucdir_finalize_weights(h))
+        self._wkey = key
+        self._gkey = None
+
+    def prepare_guide(self, guide, pad_mode=1):
+        L = _lib.load()
+        self._sync_weights()
+        guide = guide.contiguous().float()
+        key = (guide.data_ptr(), guide._version, tuple(guide.shape), pad_mode)
+        if key != self._gkey:
+            B, _, H, W = guide.shape
+            _lib.check(L.ucdir_prepare_guide(self._handle(), _ptr(guide), B, H, W, pad_mode, _stream_ptr()))
+            self._gkey = key
+            self._guide_keepalive = guide
+
+    def forward_split(self, cond, x_t, noise_level, guide, pad_mode=1):
+        """eps for cat[cond, x_t] without materialising the concat (model/diffusion.py:166)."""
+        L = _lib.load()
+        self.prepare_guide(guide, pad_mode)
+        cond = cond.contiguous().float()
+        x_t = x_t.contiguous().float()
+        lvl = noise_level.reshape(-1).contiguous().float()
+        if lvl.numel() != cond.shape[0]:
+            raise ValueError("noise_level must have one entry per sample")
+        eps = torch.empty_like(x_t)
+        B, _, H, W = x_t.shape
+        self._last_shape = (B, (H // 32 + 1) * 32, (W // 32 + 1) * 32) if pad_mode else (B, H, W)
+        _lib.check(L.ucdir_unet_forward(self._handle(), _ptr(cond), _ptr(x_t), _ptr(lvl), _ptr(eps), _stream_ptr()))
+        return eps
+
+    def naiveforward(self, x, time, guide):
+        """model/ucdir.py:270-293 (H, W multiples of 32, no padding)."""
+        return self.forward_split(x[:, :3], x[:, 3:], time, guide, pad_mode=0)
+
+    def forward(self, x, time, guide):
+        """model/ucdir.py:295-307."""
+        _, _, h, w = x.shape
+        if h * w > self.patch_threshold:
+            return patch_forward_guide(x, self.naiveforward, params={"time": time, "guide": guide},
+                                       skip=self.patch_skip, padding=self.patch_padding)
+        return self.forward_split(x[:, :3], x[:, 3:], time, guide, pad_mode=1)
+
+    def debug_read(self, layer, what="out"):
+        """Activation of ``layer`` from the last forward as (B,C,Hc,Wc) fp32 (tests)."""
+        L = _lib.load()
+        from .spec import unet_layers
+        B, Hc, Wc = self._last_shape
+        for Ld in unet_layers(self.cfg):
+            if Ld.name == layer:
+                lvl = Ld.level + (1 if Ld.kind == "down" else (-1 if Ld.kind == "up" else 0))
+                out = torch.empty(B, Ld.cout, Hc >> lvl, Wc >> lvl, device=next(self.parameters()).device)
+                _lib.check(L.ucdir_debug_read(self._handle(), layer.encode(), what.encode(), _ptr(out), out.numel(),
+                                              _stream_ptr()))
+                return out
+        raise KeyError(layer)
+
+    def forward_flops(self):
+        return float(_lib.load().ucdir_forward_flops(self._handle()))
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().ucdir_destroy(self._h)
+        except Exception:
+            pass
+
+
+def sampler_step_(x_t, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma):
+    """In-place ancestral update on the device (model/diffusion.py:150-158,171-183)."""
+    L = _lib.load()
+    if not (x_t.is_cuda and x_t.is_contiguous() and x_t.dtype == torch.float32):
+        raise _lib.UcdirError("sampler_step_ needs contiguous fp32 CUDA tensors")
+    nz = _ptr(noise) if noise is not None else ctypes.c_void_p(0)
+    _lib.check(L.ucdir_sampler_step(_ptr(x_t), _ptr(eps.contiguous()), nz, x_t.numel(), float(c_recip),
+                                    float(c_recipm1), float(coef1), float(coef2), float(sigma), _stream_ptr()))
+    return x_t
+
+
+class UNetSeeInDark(nn.Module):
+    """Initial-restoration predictor (model/ucdir.py:310-416); parameter names match the reference."""
+
+    def __init__(self, in_channels=3, out_channels=3):
+        super().__init__()
+        for name, shape in predictor_param_shapes(in_channels, out_channels).items():
+            t = torch.empty(shape)
+            if name.endswith("weight"):
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            else:
+                nn.init.uniform_(t, -0.05, 0.05)
+            _attach(self, name, nn.Parameter(t))
+
+    def _c3(self, t, n):
+        m = self._modules[n]
+        t = F.conv2d(t, m.weight, m.bias, padding=1)
+        return torch.max(0.2 * t, t)
+
+    def forward(self, x):
+        _, _, h, w = x.shape
+        ph, pw = (h // 32 + 1) * 32 - h, (w // 32 + 1) * 32 - w
+        t = F.pad(x, (0, pw, 0, ph), mode="reflect")
+        enc = []
+        for lvl in range(1, 5):
+            t = self._c3(self._c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
+            enc.append(t)
+            t = F.max_pool2d(t, 2)
+        t = self._c3(self._c3(t, "conv5_1"), "conv5_2")
+        for lvl in range(6, 10):
+            up = self._modules[f"upv{lvl}"]
+            t = F.conv_transpose2d(t, up.weight, up.bias, stride=2)
+            t = torch.cat([t, enc.pop()], dim=1)
+            t = self._c3(self._c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
+        last = self._modules["conv10_1"]
+        return F.conv2d(t, last.weight, last.bias)[..., :-ph, :-pw]
