@@ -102,6 +102,14 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
 int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst,
                          int64_t dst_elems, void* stream);
 int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
+/* Per-launch HIP-event timing of the GEMM-core kernels (bench.py's roofline leg).  While enabled,
+ * every launch is bracketed by events on its stream; ucdir_profile_read synchronises the stream and
+ * aggregates per kernel instantiation: key = 100*[TM==128] + 10*[AKGM epilogue] + column mode
+ * (0 stride-1, 1 down, 2 up, 3 plain GEMM, 4 compact-in), launches, total ms, algorithmic FLOPs
+ * (2*MAC of the un-padded problem) and algorithmic bytes (operands + output once). */
+int32_t ucdir_profile_enable(int32_t on);
+int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double* ms, double* flops,
+                           double* bytes, int32_t* nrows, void* stream);
 /* algorithmic FLOPs of one forward at the prepared shape (2*MAC, reference op count) */
 double  ucdir_forward_flops(const ucdir_ctx* ctx);
 

@@ -1,0 +1,115 @@
+"""GPU parity tests (run with ``pytest -m gpu`` on an MI355X): HIP path (through the C ABI) vs the CPU oracle.
+
+Tolerances are stated in tests/hip_checks.py: bf16 operands / fp32 accumulate / bf16 activations.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hip_checks as C  # noqa: E402
+from ucdir_amd.spec import UNetConfig  # noqa: E402
+
+SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn_res=(32,), image_size=128)
+SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, attn_res=(16,), image_size=128)
+
+OP_TOL = 4e-3        # single operator, bf16-representable inputs
+FWD_TOL = 2.5e-2     # full forward (61 GroupNorms deep), measured ~1.1-1.5e-2
+
+
+@pytest.fixture(scope="module")
+def sid_net():
+    return C.build_net(SID)
+
+
+@pytest.mark.parametrize("args", [
+    (2, 20, 20, 64, 0, 64, 3, 0, False, False, False),     # plain 3x3, TM=64, ragged tile
+    (2, 24, 40, 64, 0, 128, 3, 0, True, True, False),      # GroupNorm fold + swish
+    (2, 24, 40, 128, 64, 128, 3, 0, True, True, False),    # cat input (ups blocks)
+    (1, 33, 17, 128, 64, 64, 3, 0, True, True, False),     # odd sizes
+    (2, 32, 32, 128, 0, 128, 3, 1, False, False, False),   # Downsample
+    (2, 16, 16, 128, 0, 128, 3, 2, False, False, False),   # Upsample
+    (1, 16, 24, 64, 0, 64, 3, 2, False, False, False),
+    (2, 24, 40, 128, 64, 64, 1, 0, False, False, True),    # res_conv 1x1 + residual
+    (1, 12, 12, 512, 0, 512, 1, 0, True, False, False),    # qkv-like 1x1 with GN fold
+])
+def test_conv_gemm(args):
+    m = C.conv_case(*args)
+    assert not m["nan"]
+    assert m["rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m     # border classes of the GN fold
+    assert m["stats_rel"] < 1e-3, m                                    # GroupNorm partial sums
+
+
+@pytest.mark.parametrize("Cc", [64, 128, 256, 512])
+def test_akgm(Cc):
+    m = C.akgm_case(2, Cc, 20, 24)
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.06, m
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18)])
+def test_attention(shape):
+    m = C.attention_case(*shape)
+    assert not m["nan"] and m["rel_rms_branch"] < 1.2e-2, m
+
+
+def test_sampler_step_exact():
+    for k, m in C.sampler_step_case().items():
+        assert m["max_abs"] < 2e-6, (k, m)       # fp32 point-wise; differences are FMA contraction only
+
+
+def test_forward_small_vs_oracle_and_golden(golden_dir):
+    out, eps, ref = C.forward_case(SMALL, 2, 64, 48, [0.0029, 0.6], seed=11, taps=True)
+    assert out["eps"]["rel_rms"] < FWD_TOL, out["eps"]
+    for k, m in out.items():
+        assert not m["nan"] and m["rel_rms"] < FWD_TOL, (k, m)
+    g = np.load(os.path.join(golden_dir, "small_forward.npz"))       # output of the real reference
+    gm = C.metrics(eps, torch.from_numpy(g["eps"].astype(np.float32)))
+    assert gm["rel_rms"] < FWD_TOL, gm
+
+
+def test_forward_sid_full_config(golden_dir, sid_net):
+    out, eps, ref = C.forward_case(SID, 1, 256, 256, [0.239415851], seed=21, taps=False, net_sd=sid_net)
+    assert out["eps"]["rel_rms"] < FWD_TOL, out["eps"]
+    g = np.load(os.path.join(golden_dir, "sid_forward.npz"))         # crops of the real reference's output
+    crop = eps[0, :, 100:132, 60:92]
+    gm = C.metrics(crop, torch.from_numpy(g["eps1_crop"]))
+    assert gm["rel_rms"] < 2 * FWD_TOL, gm
+
+
+def test_forward_batch_is_independent(sid_net):
+    """B samples in one launch == B single launches (per-sample GroupNorm statistics)."""
+    net, sd = sid_net
+    from ucdir_amd.weights import synth_inputs
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(3, 96, 64, seed=3))
+    lvl = torch.tensor([[0.1], [0.5], [0.9]])
+    with torch.no_grad():
+        full = net.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda()).cpu()
+        one = net.denoise_fn(torch.cat([cond[1:2], x_t[1:2]], 1).cuda(), lvl[1:2].cuda(), guide[1:2].cuda()).cpu()
+    assert torch.equal(full[1:2], one)          # bit exact: same tiles, same reduction order
+
+
+def test_sampler_8_steps_psnr(sid_net):
+    m = C.sampler_case(SID, 64, 64, 8, net_sd=sid_net)
+    assert m["psnr_u8"] > 35.0, m               # bf16 bound from SURVEY.md §8c
+
+
+def test_patch_split_matches_oracle():
+    """Inter-step patch split (utils/util.py:108-146) with a small threshold: windows batched on the GPU."""
+    from oracle import ucdir_oracle as O
+    from ucdir_amd.weights import synth_inputs
+    net, sd = C.build_net(SMALL)
+    net.denoise_fn.patch_threshold = 0
+    net.denoise_fn.patch_skip, net.denoise_fn.patch_padding = 128, 32
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(1, 160, 200, seed=5))
+    lvl = torch.tensor([[0.5]])
+    x6 = torch.cat([cond, x_t], 1)
+    ref = O.dy3h_forward(sd, x6, lvl, guide, patch_threshold=0, skip=128, padding=32)
+    with torch.no_grad():
+        got = net.denoise_fn(x6.cuda(), lvl.cuda(), guide.cuda())
+    m = C.metrics(got, ref)
+    assert m["rel_rms"] < FWD_TOL, m

@@ -93,6 +93,20 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// ---- optional per-launch HIP-event timing (bench.py roofline) -------------------------------------
+struct ProfEntry { int key; double flops; double bytes; hipEvent_t e0, e1; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfEntry> entries;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; HIPC(hipEventCreate(&e)); pool.push_back(e); }
+        return pool[used++];
+    }
+    ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+static Profiler g_prof;
+
 template <int TM, int EPI, int MODE>
 static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
@@ -103,7 +117,38 @@ static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((cgemm_kernel<TM, EPI, MODE>), grid, dim3(CG_THREADS), lds, st, p);
 }
 
+// algorithmic work of one launch: 2*MAC of the un-padded problem; bytes = operands read once + output once
+static void gemm_work(const GemmP& p, int epi, double& flops, double& bytes) {
+    const double cols = (p.cols_mode == COLS_PLAIN) ? (double)p.W : (double)p.H * p.W;
+    if (epi == EPI_AKGM) {
+        const double C = 8.0 * p.cg;
+        flops = 2.0 * 9 * C * C * cols * p.nbatch;
+        bytes = (2.0 * C * cols * 2 + C * cols * 2 + cols * 32) * p.nbatch + 9.0 * C * C * 2;
+    } else {
+        const double K = (double)p.ntaps * p.cg;
+        flops = 2.0 * K * p.nfeat * cols * p.nbatch;
+        double in_cols = cols;
+        if (p.cols_mode == COLS_DOWN) in_cols = cols * 4; else if (p.cols_mode == COLS_UP) in_cols = cols / 4;
+        bytes = ((double)p.cg * in_cols * 2 + (double)p.nfeat * cols * (p.out_f32 ? 4 : 2) + (p.res ? (double)p.nfeat * cols * 2 : 0)) * p.nbatch
+                + (p.a_bstride ? (double)p.nfeat * K * 2 * p.nbatch : (double)p.nfeat * K * 2);
+    }
+}
+
+static void launch_cgemm_impl(const GemmP& p, int TM, int epi, hipStream_t st);
 static void launch_cgemm(const GemmP& p, int TM, int epi, hipStream_t st) {
+    if (!g_prof.on) { launch_cgemm_impl(p, TM, epi, st); return; }
+    ProfEntry e;
+    int mode = p.cols_mode; if (mode == COLS_S1 && p.in_compact) mode = MODE_S1C;
+    e.key = (TM == 128 ? 100 : 0) + (epi == EPI_AKGM ? 10 : 0) + (epi == EPI_AKGM ? 0 : mode);
+    gemm_work(p, epi, e.flops, e.bytes);
+    e.e0 = g_prof.get(); e.e1 = g_prof.get();
+    HIPC(hipEventRecord(e.e0, st));
+    launch_cgemm_impl(p, TM, epi, st);
+    HIPC(hipEventRecord(e.e1, st));
+    g_prof.entries.push_back(e);
+}
+
+static void launch_cgemm_impl(const GemmP& p, int TM, int epi, hipStream_t st) {
     const int nblk = p.nbatch * p.tiles * p.rowtiles;
     const size_t lds = cgemm_lds_bytes(TM, epi, p.groups_per_wg);
     dim3 grid(nblk);
@@ -254,7 +299,6 @@ static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C) {
 static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Act& y, AttnBufs& a, hipStream_t st) {
     const int C = x.C, N = x.H * x.W, B = x.B, Npad = ((N + 63) / 64) * 64;
     require(C % 128 == 0, "attention: channels must be a multiple of 128");
-    require(N % 8 == 0, "attention: token count must be a multiple of 8");
     require((size_t)N <= (size_t)a.N && C == a.C && B <= a.B, "attention buffers too small");
     // 1. q,k,v = conv1x1(GN(x))   (GroupNorm folded; output compact [B][N][3C])
     {
@@ -744,6 +788,32 @@ int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, fl
         return 0;
     }
     throw std::runtime_error(std::string("unknown layer ") + layer);
+    API_END
+}
+
+int32_t ucdir_profile_enable(int32_t on) {
+    API_BEGIN
+    g_prof.on = on != 0;
+    API_END
+}
+
+// Aggregate recorded launches per kernel instantiation.  Arrays have room for `cap` rows:
+// key (100*[TM==128] + 10*[AKGM] + mode), launches, total ms, algorithmic flops, algorithmic bytes.
+int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double* ms, double* flops, double* bytes,
+                           int32_t* nrows, void* stream) {
+    API_BEGIN
+    HIPC(hipStreamSynchronize((hipStream_t)stream));
+    std::map<int, int> idx; int n = 0;
+    for (auto& e : g_prof.entries) {
+        float t = 0.f; HIPC(hipEventElapsedTime(&t, e.e0, e.e1));
+        auto it = idx.find(e.key);
+        int r;
+        if (it == idx.end()) { if (n >= cap) continue; r = n++; idx[e.key] = r; keys[r] = e.key; launches[r] = 0; ms[r] = 0; flops[r] = 0; bytes[r] = 0; }
+        else r = it->second;
+        launches[r] += 1; ms[r] += t; flops[r] += e.flops; bytes[r] += e.bytes;
+    }
+    *nrows = n;
+    g_prof.entries.clear(); g_prof.used = 0;
     API_END
 }
 

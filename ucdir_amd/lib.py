@@ -40,6 +40,9 @@ _SIGS = {
                                      c_float, c_void_p]),
     "ucdir_debug_read": (c_int32, [c_void_p, c_char_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "ucdir_workspace_bytes": (c_int64, [c_void_p]),
+    "ucdir_profile_enable": (c_int32, [c_int32]),
+    "ucdir_profile_read": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), POINTER(c_double),
+                                     POINTER(c_double), POINTER(c_int32), c_void_p]),
     "ucdir_forward_flops": (c_double, [c_void_p]),
     "ucdir_op_conv": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
