@@ -366,7 +366,15 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
-        if (p.out_f32) {
+        if (p.out_nchw) {
+            const int y = cp / p.Wp - 1, x = cp - (y + 1) * p.Wp - 1;
+            if (y < p.crop_h && x < p.crop_w) {
+                float* op = reinterpret_cast<float*>(p.out) + (((long long)b * p.nfeat + f) * p.crop_h + y) * p.crop_w + x;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (f + i < p.nfeat) op[(long long)i * p.crop_h * p.crop_w] = v[i];
+            }
+        } else if (p.out_f32) {
             float* op = reinterpret_cast<float*>(p.out) + (long long)b * p.out_bstride + opos * p.out_ld + p.out_coff + f;
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);

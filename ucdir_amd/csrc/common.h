@@ -64,6 +64,7 @@ struct GemmP {
     const float* bias; const float* Tb; const float* Tg; int tab_ld;  // tables [ncls][tab_ld]
     const bf16_t* res; long long res_bstride; int res_ld; int res_coff;
     void* out; long long out_bstride; int out_ld; int out_coff; int out_f32; int out_compact;
+    int out_nchw; int crop_h, crop_w;   // final conv: fp32 NCHW (B, nfeat, crop_h, crop_w)
     int nfeat;               // valid output features (rows) in total
     float* partials; int npart;
     // AKGM

@@ -444,7 +444,9 @@ struct ucdir_ctx {
     std::vector<LayerW> lw;
     int nblocks = 0;
     float *mlp_w1 = nullptr, *mlp_b1 = nullptr, *mlp_w2 = nullptr, *mlp_b2 = nullptr, *tw = nullptr;
-    float *fin_gamma = nullptr, *fin_beta = nullptr, *fin_w = nullptr, *fin_b = nullptr;
+    float *fin_gamma = nullptr, *fin_beta = nullptr;
+    ConvW fin_conv;
+    Act fin_act;                        // swish(GN(x)) feeding the final conv
     // shape-dependent state
     DevPool apool;
     int B = 0, H = 0, W = 0, Hc = 0, Wc = 0, pad_mode = 1;
@@ -550,15 +552,8 @@ static void finalize_weights(ucdir_ctx* c) {
     const int fc = inner * cfg.channel_mults[0];
     c->fin_gamma = c->wpool.upload(W_(c, "final_conv.0.weight", fc));
     c->fin_beta = c->wpool.upload(W_(c, "final_conv.0.bias", fc));
-    {
-        const auto& fw = W_(c, "final_conv.3.weight", (size_t)cfg.out_channel * fc * 9);
-        require(cfg.out_channel <= 4, "final conv supports out_channel <= 4");
-        std::vector<float> t((size_t)9 * fc * 4, 0.f);
-        for (int o = 0; o < cfg.out_channel; ++o) for (int ci = 0; ci < fc; ++ci) for (int k = 0; k < 9; ++k)
-            t[((size_t)k * fc + ci) * 4 + o] = fw[((size_t)o * fc + ci) * 9 + k];
-        c->fin_w = c->wpool.upload(t);
-        c->fin_b = c->wpool.upload(W_(c, "final_conv.3.bias", cfg.out_channel));
-    }
+    c->fin_conv = upload_conv(c->wpool, W_(c, "final_conv.3.weight", (size_t)cfg.out_channel * fc * 9).data(),
+                              W_(c, "final_conv.3.bias", cfg.out_channel).data(), nullptr, nullptr, cfg.out_channel, fc, 3);
     c->host.clear();
     c->finalized = true;
 }
@@ -613,6 +608,7 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     (void)level;
     fl += 2.0 * 9 * c->cfg.inner_channel * c->cfg.channel_mults[0] * c->cfg.out_channel * c->Hc * c->Wc;
     c->flops = fl * B;
+    c->fin_act = make_act(c->apool, B, c->Hc, c->Wc, c->cfg.inner_channel * c->cfg.channel_mults[0], false);
     if (maxN > 0) alloc_attn(c->apool, c->attn, B, maxN, attC);
     c->attw = (float*)c->apool.alloc((size_t)c->nblocks * B * 8 * sizeof(float));
     c->guide_ready = false;
@@ -660,15 +656,24 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         cur = &r.out;
         if (d.push_skip) skips.push_back(cur);
     }
-    // final_conv
+    // final_conv: swish(GN(x)) (HBM-bound pass) then conv3x3 C -> out_channel on the MFMA core, fp32 NCHW crop
     {
         const int C = cur->C;
-        const size_t sm = (size_t)(2 * C + 9 * C * 4) * sizeof(float);
-        dim3 grid((c->H * c->W + 255) / 256, 1, B);
-        hipLaunchKernelGGL(final_kernel, grid, dim3(256), sm, st, cur->p, c->Hc, c->Wc, C, cur->stats,
-                           1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b,
-                           c->cfg.out_channel, eps, c->H, c->W);
+        hipLaunchKernelGGL(gn_silu_kernel, dim3(2048, 1, B), dim3(256), 0, st, cur->p, c->fin_act.p, c->Hc, c->Wc, C,
+                           cur->stats, 1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta);
         HIPC(hipGetLastError());
+        const ConvW& w = c->fin_conv;
+        const Act& x0 = c->fin_act;
+        GemmP p; zero_gemm(p);
+        p.A = w.A; p.a_ld = w.Kpad; p.a_rows = w.rows_pad;
+        p.B0 = x0.p; p.b0_bstride = x0.bstride(); p.ld0 = C; p.c0 = C;
+        p.cols_mode = COLS_S1; p.H = x0.H; p.W = x0.W; p.Wp = x0.W + 2; p.Hi = x0.H; p.Wi = x0.W; p.Wpi = p.Wp;
+        p.p0 = p.Wp + 1; p.pn = (x0.H - 1) * p.Wp + x0.W;
+        p.ntaps = 9; p.cg = C; p.cpt = C / 8; p.nk = w.Kpad / CG_BK;
+        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = w.rows_pad / w.TM; p.nbatch = B;
+        p.bias = w.bias; p.nfeat = w.cout;
+        p.out = eps; p.out_nchw = 1; p.crop_h = c->H; p.crop_w = c->W;
+        launch_cgemm(p, w.TM, EPI_STD, st);
     }
 }
 

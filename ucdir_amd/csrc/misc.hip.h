@@ -146,57 +146,43 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ con
 }
 
 // ------------------------------------------------------------------------------------------------
-// final_conv: GroupNorm(1) -> Swish -> conv3x3 C -> cout (<= 4), output NCHW fp32 cropped to
-// H x W (model/ucdir.py:266-268, :307).  N = 3 output channels: VALU.
-// grid (ceil(H*W/256), 1, B); w: [9][C][4] fp32 (zero padded), gamma/beta [C]
+// y = swish(GroupNorm(x)) on the valid region (final_conv.0-1, model/ucdir.py:266-267); the zero
+// border of y stays zero so the following 3x3 conv sees the reference's zero padding.
+// HBM-bound: 16 B per lane in, 16 B out.  grid (blocks, 1, B)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void final_kernel(const bf16_t* __restrict__ x, int Hc, int Wc, int C,
-                                                    const double* __restrict__ stats, double inv_count,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    const float* __restrict__ w, const float* __restrict__ bias, int cout,
-                                                    float* __restrict__ out, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float* sa = fsm;               // [C] scale
-    float* sb = fsm + C;           // [C] shift
-    float* sw = fsm + 2 * C;       // [9][C][4]
+__global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int H, int W, int C,
+                                                      const double* __restrict__ stats, double inv_count,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int b = blockIdx.z;
+    float mean, rstd;
     {
         double m = stats[b * 2] * inv_count;
         double var = stats[b * 2 + 1] * inv_count - m * m;
         if (var < 0) var = 0;
-        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + 1e-5));
-        for (int c = threadIdx.x; c < C; c += 256) { sa[c] = rstd * gamma[c]; sb[c] = beta[c] - mean * rstd * gamma[c]; }
-        for (int i = threadIdx.x; i < 9 * C * 4; i += 256) sw[i] = w[i];
+        mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
-    __syncthreads();
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= H * W) return;
-    const int y = pix / W, xq = pix % W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const long long bs = (long long)(Hc + 2) * (Wc + 2) * C;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky;           // padded coords: valid rows are 1..Hc
-        if (yy < 1 || yy > Hc) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xx = xq + kx;
-            if (xx < 1 || xx > Wc) continue;
-            const bf16_t* px = x + b * bs + ((long long)yy * (Wc + 2) + xx) * C;
-            const float* wt = sw + (ky * 3 + kx) * C * 4;
-            for (int c = 0; c < C; c += 8) {
-                const uint4 v = *reinterpret_cast<const uint4*>(px + c);
-                const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+    const int c8n = C / 8;
+    const long long bs = (long long)(H + 2) * (W + 2) * C;
+    const long long n = (long long)H * W * c8n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8;
+        const long long pix = i / c8n;
+        const int yy = (int)(pix / W), xx = (int)(pix % W);
+        const long long off = b * bs + ((long long)(yy + 1) * (W + 2) + xx + 1) * C + c;
+        const uint4 v = *reinterpret_cast<const uint4*>(x + off);
+        const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float f = bf2f(h[k]) * sa[c + k] + sb[c + k];
-                    f = f / (1.0f + __expf(-f));
-                    const float4 w4 = *reinterpret_cast<const float4*>(wt + (c + k) * 4);
-                    acc[0] += f * w4.x; acc[1] += f * w4.y; acc[2] += f * w4.z; acc[3] += f * w4.w;
-                }
-            }
+        for (int k = 0; k < 8; ++k) {
+            float f = (bf2f(h[k]) - mean) * rstd * gg[k] + bb[k];
+            oh[k] = f2bf(silu_f(f));
         }
+        *reinterpret_cast<uint4*>(y + off) = ov;
     }
-    for (int co = 0; co < cout; ++co)
-        out[(((long long)b * cout + co) * H + y) * W + xq] = acc[co] + bias[co];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ static inline PackedConv pack_conv(const float* w, const float* bias, const floa
     P.Kpad = ((P.ntaps * cin + 63) / 64) * 64;
     P.rows_pad = ((cout + TM - 1) / TM) * TM;
     P.A.assign((size_t)P.rows_pad * P.Kpad, 0);
-    P.bias.assign(cout, 0.f);
+    P.bias.assign(P.rows_pad, 0.f);        // padded: the epilogue reads 8 features at a time
     if (bias) for (int o = 0; o < cout; ++o) P.bias[o] = bias[o];
     P.ncls = (ks == 3) ? 9 : 1;
     const bool fold = gamma != nullptr;

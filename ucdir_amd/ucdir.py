@@ -124,13 +124,13 @@ class DY3h(nn.Module):
     def prepare_guide(self, guide, pad_mode=1):
         L = _lib.load()
         self._sync_weights()
-        guide = guide.contiguous().float()
-        key = (guide.data_ptr(), guide._version, tuple(guide.shape), pad_mode)
+        key = (guide.data_ptr(), guide._version, tuple(guide.shape), tuple(guide.stride()), pad_mode)
         if key != self._gkey:
-            B, _, H, W = guide.shape
-            _lib.check(L.ucdir_prepare_guide(self._handle(), _ptr(guide), B, H, W, pad_mode, _stream_ptr()))
+            g = guide.contiguous().float()
+            B, _, H, W = g.shape
+            _lib.check(L.ucdir_prepare_guide(self._handle(), _ptr(g), B, H, W, pad_mode, _stream_ptr()))
             self._gkey = key
-            self._guide_keepalive = guide
+            self._guide_keepalive = (guide, g)
 
     def forward_split(self, cond, x_t, noise_level, guide, pad_mode=1):
         """eps for cat[cond, x_t] without materialising the concat (model/diffusion.py:166)."""
