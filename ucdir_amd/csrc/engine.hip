@@ -12,6 +12,7 @@
 
 #include "../../include/ucdir_hip.h"
 #include "cgemm.hip.h"
+#include "akgm64.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -83,7 +84,7 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     return W;
 }
 static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
-    PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C);
+    PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, C == 64 ? 80 : 0);   // C == 64: dedicated kernel, exact K
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
@@ -246,12 +247,48 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
 }
 
+// C == 64 (full-resolution level): dedicated halo-tile kernel (akgm64.hip.h)
+static float* g_tc64 = nullptr; static size_t g_tc64_cap = 0;
+static void run_akgm64(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(hipFuncSetAttribute((const void*)akgm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A64_LDS));
+        attr_done = true;
+    }
+    const size_t need = (size_t)y.B * 9 * 512 * sizeof(float);
+    if (need > g_tc64_cap) { if (g_tc64) (void)hipFree(g_tc64); HIPC(hipMalloc((void**)&g_tc64, need)); g_tc64_cap = need; }
+    const double inv = 1.0 / (64.0 * h1.H * h1.W);
+    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv, w.bias, w.Tb, w.Tg, 512, g_tc64);
+    Akgm64P p;
+    p.A = w.A; p.h = h1.p; p.h_bstride = h1.bstride();
+    p.H = y.H; p.W = y.W; p.Wp = y.W + 2; p.p0 = p.Wp + 1; p.pn = (y.H - 1) * p.Wp + y.W;
+    p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.nbatch = y.B;
+    p.stats = h1.stats; p.inv_count = inv; p.Tc = g_tc64;
+    p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
+    p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
+    p.npart = p.tiles; require(p.npart <= y.npart, "run_akgm64: partial buffer too small");
+    p.partials = y.partials;
+    if (g_prof.on) {
+        ProfEntry e; e.key = 11; e.flops = 2.0 * 9 * 64 * 64 * (double)y.H * y.W * y.B;
+        e.bytes = (3.0 * 64 * 2 + 32) * (double)y.H * y.W * y.B; e.e0 = g_prof.get(); e.e1 = g_prof.get();
+        HIPC(hipEventRecord(e.e0, st));
+        hipLaunchKernelGGL(akgm64_kernel, dim3(y.B * p.tiles), dim3(CG_THREADS), A64_LDS, st, p);
+        HIPC(hipEventRecord(e.e1, st));
+        g_prof.entries.push_back(e);
+    } else {
+        hipLaunchKernelGGL(akgm64_kernel, dim3(y.B * p.tiles), dim3(CG_THREADS), A64_LDS, st, p);
+    }
+    HIPC(hipGetLastError());
+    y.npart = p.npart; finalize_stats(y, st);
+}
+
 // AKGM tail of a block: y = swish(sum_s spdyconv(GN2(h1))[c,s] * G[s] * attw[s]) + res
 static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y,
                      hipStream_t st) {
-    GemmP p; zero_gemm(p);
     const int C = w.C;
     require(C == 64 || C % 128 == 0, "AKGM: channel count must be 64 or a multiple of 128");
+    if (C == 64) { run_akgm64(w, h1, G, attw, res, y, st); return; }
+    GemmP p; zero_gemm(p);
     const int TM = (C == 64) ? 64 : 128;
     p.A = w.A; p.a_ld = w.Kpad; p.a_rows = C; p.a_gstride = (long long)C * w.Kpad;
     p.B0 = h1.p; p.b0_bstride = h1.bstride(); p.ld0 = C; p.c0 = C;

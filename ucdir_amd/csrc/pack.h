@@ -81,11 +81,12 @@ struct PackedAkgm {
 };
 
 // wsp: [8C][C/8][3][3], bsp: [8C], gamma/beta: [C] (norm2)
-static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
+static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const float* gamma, const float* beta, int C,
+                                   int kpad_override = 0) {
     PackedAkgm P;
     P.C = C; P.cg = C / 8;
     const int cg = P.cg;
-    P.Kpad = ((9 * cg + 63) / 64) * 64;
+    P.Kpad = kpad_override ? kpad_override : ((9 * cg + 63) / 64) * 64;
     P.A.assign((size_t)8 * C * P.Kpad, 0);
     P.bias.assign((size_t)8 * C, 0.f);
     P.Tb.assign((size_t)9 * 8 * C, 0.f);
