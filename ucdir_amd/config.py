@@ -1,0 +1,78 @@
+"""Config parsing for ``sr.py`` (reference: core/logger.py:22-199, re-done on PyYAML).
+
+Keeps the YAML schema of config/sid.yaml and the name-keyed validation overrides the reference
+hard-codes: phase ``val`` prefixes the name with ``val_``, names containing ``sid`` sample with
+T = 50, linear_end = 0.4 (core/logger.py:58-61); GoPro / JPEG names keep their own tables
+(core/logger.py:63-136); ``-ema`` is appended when the EMA scheduler is on (:141-142); the
+experiment directory is ``experiments/{timestamp}_{name}_s{T}`` (:144-154).
+"""
+import os
+from datetime import datetime
+
+import yaml
+
+
+class NoneDict(dict):
+    """dict returning None for missing keys (core/logger.py:202-217)."""
+
+    def __missing__(self, key):
+        return None
+
+
+def to_nonedict(o):
+    if isinstance(o, dict):
+        return NoneDict({k: to_nonedict(v) for k, v in o.items()})
+    if isinstance(o, list):
+        return [to_nonedict(v) for v in o]
+    return o
+
+
+def get_timestamp():
+    return datetime.now().strftime("%y%m%d_%H%M%S")
+
+
+def parse(args, world_size=1, make_dirs=True):
+    with open(args.config) as f:
+        opt = yaml.safe_load(f)
+    phase = args.phase
+    if getattr(args, "debug", False):
+        opt["name"] = "debug_{}".format(opt["name"])
+    if phase == "val":
+        opt["name"] = "val_{}".format(opt["name"])
+    fix = ""
+    if phase == "val":
+        opt["path"]["resume_state"] = args.checkpoint
+        da = opt["datasets"]["val"]["data_args"]
+        da["data_len"] = -1
+        if "sr-" in opt["name"]:
+            da["data_len"] = 5000
+        da["split"] = "val"
+        sched = opt["model"]["beta_schedule"]["val"]
+        name = opt["name"]
+        if "sid" in name:
+            sched["n_timestep"], sched["linear_end"] = 50, 4e-1
+        elif "gop-" in name:
+            sched["n_timestep"], sched["linear_end"] = 50, 4e-1
+        elif "jpeg" in name or "img" in name:
+            sched["n_timestep"], sched["linear_end"] = 50, 4e-1
+        if opt.get("train", {}).get("ema_scheduler", {}).get("use"):
+            opt["name"] += "-ema"
+    root = os.path.join("experiments", "{}_{}".format(get_timestamp(), opt["name"]))
+    if phase == "val":
+        root += "_s{}".format(opt["model"]["beta_schedule"]["val"]["n_timestep"]) + fix
+    opt["path"]["experiments_root"] = root
+    for key, path in list(opt["path"].items()):
+        if "resume" not in key and "experiments" not in key:
+            opt["path"][key] = os.path.join(root, path)
+            if make_dirs:
+                os.makedirs(opt["path"][key], exist_ok=True)
+    opt["phase"] = phase
+    opt["distributed"] = True
+    bs = opt["datasets"]["train"]["batch_size"]
+    opt["datasets"]["train"]["batch_size"] = bs // max(world_size, 1)
+    if "debug" in opt["name"]:
+        opt["model"]["beta_schedule"]["train"]["n_timestep"] = 10
+        opt["model"]["beta_schedule"]["val"]["n_timestep"] = 10
+        opt["datasets"]["val"]["data_len"] = 3
+    opt["enable_wandb"] = bool(getattr(args, "enable_wandb", False))
+    return to_nonedict(opt)
