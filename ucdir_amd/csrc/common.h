@@ -22,6 +22,8 @@ __host__ __device__ inline float bf2f(bf16_t h) {
 }
 
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// swish with v_rcp_f32 instead of an IEEE divide (1 ulp; the result is rounded to bf16 anyway)
+__device__ inline float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // Activation tensor in HBM: zero-bordered NHWC bf16, [B][H+2][W+2][C].  The one-pixel zero
 // border makes every 3x3 tap of an interior pixel an in-bounds read of the right value, so the
@@ -31,7 +33,8 @@ struct Act {
     int B = 0, H = 0, W = 0, C = 0;
     double* stats = nullptr;       // [B][2] (sum, sum of squares) over the valid region
     float* partials = nullptr;     // [B][npart][2] per-workgroup partial sums
-    int npart = 0;
+    int npart = 0;                 // partial sums written by the last producer
+    int npart_cap = 0;             // capacity of `partials`
     __host__ __device__ int Hp() const { return H + 2; }
     __host__ __device__ int Wp() const { return W + 2; }
     long long bstride() const { return (long long)(H + 2) * (W + 2) * C; }
@@ -58,6 +61,8 @@ struct GemmP {
     int rowtiles;            // row tiles (grid.y equivalent)
     int groups_per_wg;       // AKGM: groups looped inside one workgroup
     int nbatch;
+    int th, tw, tiles_x, tiles_y;   // conv3x3_halo: 2-D pixel tile and tile grid per sample
+    int up_phase;                   // conv3x3_halo: nearest-x2 + 3x3 as four 2x2 parity convolutions
     // epilogue
     float alpha; int fold; int act;
     const double* stats0; const double* stats1; double inv_count;   // GN of the input (fold)
@@ -70,4 +75,5 @@ struct GemmP {
     // AKGM
     const float* G; long long g_bstride;   // guide branch, compact [B][H*W][8]
     const float* attw;                      // [B][8]
+    unsigned long long* dbg;                // UCDIR_TIMING builds: s_memtime stamps of one workgroup
 };

@@ -1,0 +1,345 @@
+// 3x3 stride-1 convolution on the matrix cores with a 2-D pixel tile and an LDS halo (gfx950).
+//
+// Why: in the shifted-GEMM kernel (cgemm.hip.h) every K step (one tap x 64 channels) re-stages a
+// fresh 16 KB activation tile and drains its loads before the next step; on MI355X that loop is
+// load-LATENCY bound (~3000 cycles per step against ~1000 cycles of MFMA).  Here
+//   * a workgroup (512 threads, 8 wave64) owns TM output features x a th x tw pixel tile
+//     (th*tw <= 256, e.g. 16x16) of one sample;
+//   * the (th+2) x (tw+2) x 64-channel input halo is staged into LDS ONCE per 64-channel chunk
+//     (double buffered, prefetched a whole chunk = 9 K steps ahead) and all 9 taps read their B
+//     fragments from it at a uniform shift: 6x less activation traffic than per-tap staging;
+//   * K advances two taps x 32 channels per step (16 MFMAs per wave between barriers); the weight
+//     tiles of the next step stream into a 2-deep ring while the current step is on the matrix
+//     cores, with raw s_barrier and counted s_waitcnt so the next chunk's halo stays in flight;
+//   * nearest-x2 Upsample + 3x3 conv (model/ucdir.py:53-60) runs here as four parity classes of
+//     2x2 convolutions on the LOW-resolution grid (taps are just other shifts into the same halo,
+//     weights pre-summed at pack time): 2.25x fewer FLOPs than convolving the upsampled image;
+//   * LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row>>1)&7 on the source side.
+// Epilogue = the same GroupNorm-fold / swish / residual / partial-sum / coalesced-store phase as
+// cgemm.hip.h, run in passes of 128 pixels through an fp32 LDS stage.
+#pragma once
+#include "cgemm.hip.h"
+
+#define HC_THREADS 512
+#define HC_HALO_PX 324
+#define HC_BK 32                                   // channels per chunk (64-byte LDS rows)
+#define HC_HALO_BYTES (HC_HALO_PX * HC_BK * 2)     // 20736
+
+// LDS: [halo x2][A ring x3] (K loop) aliased by the fp32 epilogue stage; then scalars and the
+// per-workgroup GroupNorm-fold table Tc[9][TM].  <= 80 KB so two workgroups share a CU: one
+// workgroup's prologue / epilogue overlaps the other's matrix-core loop.
+template <int TM>
+__host__ __device__ constexpr int hc_kloop_bytes() { return 2 * HC_HALO_BYTES + 2 * 2 * TM * HC_BK * 2; }
+template <int TM>
+__host__ __device__ constexpr int hc_stage_bytes() { return ((TM == 128) ? 128 : 256) * (TM + 4) * 4; }
+template <int TM>
+__host__ __device__ constexpr int hc_scal_off() { return hc_kloop_bytes<TM>() > hc_stage_bytes<TM>() ? hc_kloop_bytes<TM>() : hc_stage_bytes<TM>(); }
+template <int TM>
+__host__ __device__ constexpr int hc_lds_bytes() { return hc_scal_off<TM>() + 128 + 9 * TM * 4; }
+
+#ifdef UCDIR_TIMING
+#define HC_STAMP(i) do { if (dbg_on) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HC_STAMP(i) do {} while (0)
+#endif
+#define HC_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// s_waitcnt needs an immediate: dispatch a wave-uniform count to the literal forms
+__device__ __forceinline__ void hc_wait_vm(int n) {
+    switch (n) {
+        case 0: HC_WAIT(0); break;
+        case 1: HC_WAIT(1); break;
+        case 2: HC_WAIT(2); break;
+        case 3: HC_WAIT(3); break;
+        case 4: HC_WAIT(4); break;
+        case 5: HC_WAIT(5); break;
+        case 6: HC_WAIT(6); break;
+        default: HC_WAIT(7); break;
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WM = TM / 64;               // waves along rows
+    constexpr int NPG = 8 / WM;               // pixel groups
+    constexpr int TPW = 256 / NPG;            // pixels per wave (64 | 32)
+    constexpr int NTP = TPW / 32;             // 32-pixel MFMA tiles per wave (2 | 1)
+    constexpr int PXH = (TM == 128) ? 128 : 256;   // pixels per epilogue pass
+    unsigned char* halo = smem;
+    unsigned char* aring = smem + 2 * HC_HALO_BYTES;
+    float* scal = reinterpret_cast<float*>(smem + hc_scal_off<TM>());
+    float* tcs = scal + 32;                    // Tc[9][TM] = bias + Tb - mean*rstd*Tg
+    float* stage = reinterpret_cast<float*>(smem);
+    constexpr int SL = TM + 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NPG, wq = wave % NPG;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int par = 0;
+    if (p.up_phase) { par = lid & 3; lid >>= 2; }
+    const int py = par >> 1, pxp = par & 1;
+    const int rowtile = lid % p.rowtiles;
+    int tq = lid / p.rowtiles;
+    const int tx = tq % p.tiles_x; tq /= p.tiles_x;
+    const int ty = tq % p.tiles_y;
+    const int b = tq / p.tiles_y;
+    const int th = p.th, tw = p.tw, hw = tw + 2;
+    const int y0 = ty * th, x0 = tx * tw;
+    const int hcount = (th + 2) * hw;
+    const int nslots = th * tw;
+
+    {
+        float mean = 0.f, rstd = 1.f;
+        if (p.fold) {
+            double S = p.stats0[b * 2], Q = p.stats0[b * 2 + 1];
+            if (p.stats1) { S += p.stats1[b * 2]; Q += p.stats1[b * 2 + 1]; }
+            double m = S * p.inv_count;
+            double var = Q * p.inv_count - m * m;
+            if (var < 0) var = 0;
+            mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
+        }
+        if (tid == 0) { scal[0] = mean; scal[1] = rstd; }
+        // Tc[cls][f] = bias + Tb[cls] - mean*rstd*Tg[cls] for this workgroup's TM features (read in phase 2)
+        const float mr = mean * rstd;
+        for (int i = tid; i < 9 * TM; i += HC_THREADS) {
+            const int cls = i / TM, fl = i - cls * TM;
+            const int f = rowtile * TM + fl;
+            float v = 0.f;
+            if (f < p.nfeat || p.bias) v = p.bias ? p.bias[f] : 0.f;
+            if (p.fold && f < p.nfeat) v += p.Tb[(long long)cls * p.tab_ld + f] - mr * p.Tg[(long long)cls * p.tab_ld + f];
+            tcs[i] = v;
+        }
+    }
+
+    // ---- halo loader geometry: instruction k = i*8 + wave stages halo pixels 16k .. 16k+15 ------
+    int hsrc[3], hjsw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int hp = (i * 8 + wave) * 16 + (lane >> 2);
+        int hr = hp / hw, hc = hp - hr * hw;
+        int gy = y0 + hr, gx = x0 + hc;
+        gy = gy > p.H + 1 ? p.H + 1 : gy;
+        gx = gx > p.W + 1 ? p.W + 1 : gx;
+        hsrc[i] = (hp < hcount) ? (gy * p.Wp + gx) : -1;
+        hjsw[i] = (lane & 3) ^ ((hp >> 2) & 3);
+    }
+    const int nchunks = p.cg / HC_BK;
+    const int nh_min = ((hcount + 15) / 16) / 8;    // halo staging instructions every wave issues (some issue one more)
+    const int ntap = p.up_phase ? 4 : 9;
+    const int nsteps_c = (ntap + 1) >> 1;          // steps (tap pairs) per chunk
+    const int nk = nchunks * nsteps_c;
+    auto issue_halo = [&](int c, int buf) {
+        int ch = c * HC_BK;
+        const bf16_t* src; int ld;
+        if (ch < p.c0) { src = p.B0 + (long long)b * p.b0_bstride; ld = p.ld0; }
+        else { src = p.B1 + (long long)b * p.b1_bstride; ld = p.ld1; ch -= p.c0; }
+        src += ch;
+        unsigned char* hb = halo + buf * HC_HALO_BYTES;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if ((i * 8 + wave) * 16 < hcount) {            // wave-uniform
+                if (hsrc[i] >= 0) stage16(src + hsrc[i] * ld + hjsw[i] * 8, hb + (i * 8 + wave) * 1024, lane);
+            }
+        }
+    };
+    // ---- weight tile loader: TM rows x 64 B; 16 rows per instruction, one instruction per wave ---
+    // (TM == 64: waves 4-7 re-stage rows 0-63 with identical data so every wave issues the same count)
+    int arow_off;
+    {
+        const int row = ((wave * 16) % TM) + (lane >> 2);
+        const int ajsw = (lane & 3) ^ ((row >> 2) & 3);
+        arow_off = (rowtile * TM + row) * p.a_ld + ajsw * 8;
+    }
+    const bf16_t* Abase = p.A + (long long)par * p.a_gstride;
+    auto issue_A = [&](int c, int u, int slot) {      // taps 2u and 2u+1 (the odd tail re-stages tap 2u: uniform count)
+        unsigned char* ab = aring + slot * (2 * TM * HC_BK * 2) + ((wave * 16) % TM) * 64;
+        const int t0 = 2 * u, t1 = (2 * u + 1 < ntap) ? 2 * u + 1 : 2 * u;
+        stage16(Abase + t0 * p.cg + c * HC_BK + arow_off, ab, lane);
+        stage16(Abase + t1 * p.cg + c * HC_BK + arow_off, ab + TM * HC_BK * 2, lane);
+    };
+
+    // ---- fragment geometry -----------------------------------------------------------------------
+    int a_off[2], a_sw[2], hp0[NTP];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int row = wm * 64 + tm * 32 + (lane & 31);
+        a_off[tm] = row * 64; a_sw[tm] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+        int slot = wq * TPW + tp * 32 + (lane & 31);
+        slot = slot < nslots ? slot : nslots - 1;
+        const int r = slot / tw, c = slot - r * tw;
+        hp0[tp] = r * hw + c;
+    }
+
+    f32x16_t acc[2][NTP];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
+    int dbg_n = 0;
+#endif
+    HC_STAMP(0);
+    // ---- K loop: s = c*9 + t -------------------------------------------------------------------------
+    issue_halo(0, 0);
+    issue_A(0, 0, 0);
+    int c = 0, u = 0;                           // chunk and tap pair of the step being computed
+    for (int s = 0; s < nk; ++s) {
+        // everything older than the halo prefetch issued one step ago must have landed
+        if (u == 1 && c + 1 < nchunks) hc_wait_vm(nh_min); else { HC_WAIT(0); }
+        HC_STAMP(1);
+        asm volatile("s_barrier" ::: "memory");
+        HC_STAMP(2);
+        {
+            int cn = c, un = u + 1;
+            if (un == nsteps_c) { un = 0; ++cn; }
+            if (s + 1 < nk) issue_A(cn, un, (s + 1) & 1);
+        }
+        if (u == 0 && c + 1 < nchunks) issue_halo(c + 1, (c + 1) & 1);
+        HC_STAMP(3);
+        const unsigned char* Hb = halo + (c & 1) * HC_HALO_BYTES;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * u + tt;
+            if (t < ntap) {
+                const unsigned char* Ab = aring + (s & 1) * (2 * TM * HC_BK * 2) + tt * (TM * HC_BK * 2);
+                int sh;
+                if (p.up_phase) sh = (py + (t >> 1)) * hw + (pxp + (t & 1));
+                else { const int ky = tap_ky(t); sh = ky * hw + (t - 3 * ky); }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int kch = kk * 2 + (lane >> 5);
+                    bf16x8_t af[2], bfr[NTP];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        af[tm] = *reinterpret_cast<const bf16x8_t*>(Ab + a_off[tm] + ((kch ^ a_sw[tm]) << 4));
+#pragma unroll
+                    for (int tp = 0; tp < NTP; ++tp) {
+                        const int hp = hp0[tp] + sh;
+                        bfr[tp] = *reinterpret_cast<const bf16x8_t*>(Hb + hp * 64 + ((kch ^ ((hp >> 2) & 3)) << 4));
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tp = 0; tp < NTP; ++tp)
+                            acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+                }
+            }
+        }
+#ifdef UCDIR_TIMING
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NTP - 1][15]));
+#endif
+        HC_STAMP(4);
+        if (++u == nsteps_c) { u = 0; ++c; }
+    }
+    HC_STAMP(5);
+
+    // ---- epilogue in passes of PXH pixels ------------------------------------------------------------
+    const float rstd_s = scal[1];
+    const float alpha = p.alpha * (p.fold ? rstd_s : 1.0f);
+    const int fbase = rowtile * TM;
+    constexpr int nf8 = TM / 8;
+    float s1 = 0.f, s2 = 0.f;
+    for (int pass = 0; pass < 256 / PXH; ++pass) {
+        __syncthreads();
+        if ((wq * TPW) / PXH == pass) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tp = 0; tp < NTP; ++tp) {
+                    const int px = (wq * TPW) % PXH + tp * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
+                        *reinterpret_cast<float4*>(&stage[px * SL + f]) =
+                            make_float4(acc[tm][tp][rg * 4 + 0], acc[tm][tp][rg * 4 + 1], acc[tm][tp][rg * 4 + 2], acc[tm][tp][rg * 4 + 3]);
+                    }
+                }
+        }
+        __syncthreads();
+        for (int it = tid; it < PXH * nf8; it += HC_THREADS) {
+            const int px = it / nf8;
+            const int f8 = (it - px * nf8) * 8;
+            const int slot = pass * PXH + px;
+            if (slot >= nslots) continue;
+            const int r = slot / tw, cc = slot - r * tw;
+            const int y = y0 + r, x = x0 + cc;                 // 0-based valid coordinates
+            if (y >= p.H || x >= p.W) continue;
+            const int f = fbase + f8;
+            if (f >= p.nfeat) continue;
+            long long cp;
+            int cls = 4;
+            if (p.up_phase) cp = (long long)(2 * y + py + 1) * (2 * p.W + 2) + (2 * x + pxp + 1);
+            else {
+                cp = (long long)(y + 1) * p.Wp + (x + 1);
+                cls = (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+            }
+            float v[8];
+            {
+                const float4 a = *reinterpret_cast<const float4*>(&stage[px * SL + f8]);
+                const float4 d = *reinterpret_cast<const float4*>(&stage[px * SL + f8 + 4]);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= alpha;
+            {
+                const float4 t0 = *reinterpret_cast<const float4*>(&tcs[cls * TM + f8]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&tcs[cls * TM + f8 + 4]);
+                v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+            }
+            if (p.act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+            }
+            if (p.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);
+                const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bf2f(rh[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+            if (p.out_nchw) {
+                if (y < p.crop_h && x < p.crop_w) {
+                    float* op = reinterpret_cast<float*>(p.out) + (((long long)b * p.nfeat + f) * p.crop_h + y) * p.crop_w + x;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (f + i < p.nfeat) op[(long long)i * p.crop_h * p.crop_w] = v[i];
+                }
+            } else {
+                uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) oh[i] = f2bf(v[i]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = ov;
+            }
+        }
+    }
+    HC_STAMP(6);
+#ifdef UCDIR_TIMING
+    if (dbg_on) p.dbg[255] = dbg_n;
+#endif
+    if (p.partials) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        __syncthreads();
+        if (lane == 0) { scal[2 + wave * 2] = s1; scal[3 + wave * 2] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            float t1 = 0.f, t2s = 0.f;
+            for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2s += scal[3 + w * 2]; }
+            float* pp = p.partials + ((long long)b * p.npart + ((long long)(ty * p.tiles_x + tx) * p.rowtiles + rowtile) * (p.up_phase ? 4 : 1) + par) * 2;
+            pp[0] = t1; pp[1] = t2s;
+        }
+    }
+}

@@ -13,6 +13,7 @@
 #include "../../include/ucdir_hip.h"
 #include "cgemm.hip.h"
 #include "akgm64.hip.h"
+#include "conv_halo.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -64,6 +65,7 @@ struct DevPool {
 struct ConvW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
     int rows_pad = 0, Kpad = 0, ntaps = 0, cin = 0, cout = 0, TM = 128; bool fold = false;
+    bf16_t* Aup = nullptr; int Kup = 0;     // Upsample convs: parity-decomposed 2x2 weights [4][rows_pad][4*cin]
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -82,6 +84,10 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     if (W.fold) { W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg); }
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
     return W;
+}
+static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
+    PackedConv P = pack_upconv(w, bias, W.cout, W.cin, W.TM);
+    W.Aup = pool.upload(P.A); W.Kup = P.Kpad;
 }
 static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
     PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, C == 64 ? 80 : 0);   // C == 64: dedicated kernel, exact K
@@ -120,7 +126,8 @@ static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
 
 // algorithmic work of one launch: 2*MAC of the un-padded problem; bytes = operands read once + output once
 static void gemm_work(const GemmP& p, int epi, double& flops, double& bytes) {
-    const double cols = (p.cols_mode == COLS_PLAIN) ? (double)p.W : (double)p.H * p.W;
+    // up_phase: H, W describe the low-res input grid; the reference convolves the 2x upsampled image
+    const double cols = ((p.cols_mode == COLS_PLAIN) ? (double)p.W : (double)p.H * p.W) * (p.up_phase ? 4.0 : 1.0);
     if (epi == EPI_AKGM) {
         const double C = 8.0 * p.cg;
         flops = 2.0 * 9 * C * C * cols * p.nbatch;
@@ -196,6 +203,8 @@ static int npart_for(int H, int W, int C) {
     if (C / 16 > rt) rt = C / 16;          // AKGM launches 8*C/128 row tiles
     int stem_blocks = ((H * W + 255) / 256) * ((C + 63) / 64);
     int n = tiles * rt;
+    int halo_tiles = ((H + 3) / 4) * ((W + 15) / 16) * rt;     // generous bound for conv3x3_halo tilings
+    if (halo_tiles > n) n = halo_tiles;
     return n > stem_blocks ? n : stem_blocks;
 }
 
@@ -203,12 +212,47 @@ static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats =
     Act a; a.B = B; a.H = H; a.W = W; a.C = C;
     a.p = (bf16_t*)pool.alloc((size_t)a.elems() * sizeof(bf16_t), true);
     if (with_stats) {
-        a.npart = npart_for(H, W, C);
+        a.npart = a.npart_cap = npart_for(H, W, C);
         a.partials = (float*)pool.alloc((size_t)B * a.npart * 2 * sizeof(float), true);
         a.stats = (double*)pool.alloc((size_t)B * 2 * sizeof(double), true);
     }
     return a;
 }
+
+// pick the th x tw pixel tile (th*tw <= 256, halo <= 324 px) with the best MFMA-slot utilisation
+static void choose_tile(int H, int W, int& th, int& tw) {
+    double best = -1; th = 16; tw = 16;
+    for (int a = 1; a <= 64; ++a)
+        for (int b = 4; b <= 256; ++b) {
+            if (a * b > 256 || (a + 2) * (b + 2) > HC_HALO_PX) continue;
+            const double tiles = (double)((H + a - 1) / a) * ((W + b - 1) / b);
+            const double util = (double)H * W / (tiles * 256.0) - 1e-4 * (a + 2) * (b + 2) / 324.0;
+            if (util > best) { best = util; th = a; tw = b; }
+        }
+}
+
+template <int TM>
+static void launch_halo(const GemmP& p, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, hc_lds_bytes<TM>()));
+        attr_done = true;
+    }
+    const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1);
+    if (g_prof.on) {
+        ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
+        e.e0 = g_prof.get(); e.e1 = g_prof.get();
+        HIPC(hipEventRecord(e.e0, st));
+        hipLaunchKernelGGL((conv3x3_halo_kernel<TM>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+        HIPC(hipEventRecord(e.e1, st));
+        g_prof.entries.push_back(e);
+    } else {
+        hipLaunchKernelGGL((conv3x3_halo_kernel<TM>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+    }
+    HIPC(hipGetLastError());
+}
+
+static bool g_use_halo = true;
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
 static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
@@ -238,12 +282,44 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     p.bias = w.bias;
     if (res) { p.res = res->p; p.res_bstride = res->bstride(); p.res_ld = res->C; p.res_coff = 0; }
     p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = y.C; p.nfeat = w.cout;
+    const bool upph = g_use_halo && mode == COLS_UP && w.Aup && x0.C % 64 == 0 && !x1;
+    const bool halo = upph || (g_use_halo && mode == COLS_S1 && w.ntaps == 9 && x0.C % 64 == 0 && (!x1 || x1->C % 64 == 0));
+    if (halo) {
+        // tiles live on the INPUT grid for the parity-decomposed Upsample conv, on the output grid otherwise
+        const int gh = upph ? x0.H : y.H, gw = upph ? x0.W : y.W;
+        choose_tile(gh, gw, p.th, p.tw);
+        p.tiles_x = (gw + p.tw - 1) / p.tw; p.tiles_y = (gh + p.th - 1) / p.th;
+        p.tiles = p.tiles_x * p.tiles_y;
+        if (upph) {
+            p.up_phase = 1; p.A = w.Aup; p.a_ld = w.Kup; p.a_gstride = (long long)w.rows_pad * w.Kup;
+            p.H = x0.H; p.W = x0.W; p.Wp = x0.W + 2;          // halo geometry = input grid
+            p.tiles *= 4;
+        }
+    }
     if (want_stats) {
         p.npart = p.tiles * p.rowtiles;
-        require(p.npart <= y.npart, "run_conv: partial buffer too small");
+        require(p.npart <= y.npart_cap, "run_conv: partial buffer too small");
         p.partials = y.partials;
     }
-    launch_cgemm(p, w.TM, EPI_STD, st);
+#ifdef UCDIR_TIMING
+    static unsigned long long* dbgbuf = nullptr;
+    if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
+    HIPC(hipMemset(dbgbuf, 0, 256 * 8));
+    p.dbg = dbgbuf;
+#endif
+    if (halo) { if (w.TM == 128) launch_halo<128>(p, st); else launch_halo<64>(p, st); }
+#ifdef UCDIR_TIMING
+    if (halo) {
+        unsigned long long h[256];
+        HIPC(hipStreamSynchronize(st));
+        HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
+        const int n = (int)h[255];
+        fprintf(stderr, "TIMING n=%d:", n);
+        for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    else launch_cgemm(p, w.TM, EPI_STD, st);
     if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
 }
 
@@ -266,7 +342,7 @@ static void run_akgm64(const AkgmW& w, const Act& h1, const float* G, const floa
     p.stats = h1.stats; p.inv_count = inv; p.Tc = g_tc64;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
-    p.npart = p.tiles; require(p.npart <= y.npart, "run_akgm64: partial buffer too small");
+    p.npart = p.tiles; require(p.npart <= y.npart_cap, "run_akgm64: partial buffer too small");
     p.partials = y.partials;
     if (g_prof.on) {
         ProfEntry e; e.key = 11; e.flops = 2.0 * 9 * 64 * 64 * (double)y.H * y.W * y.B;
@@ -308,7 +384,7 @@ static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float*
     p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.npart = p.tiles * p.rowtiles;
-    require(p.npart <= y.npart, "run_akgm: partial buffer too small");
+    require(p.npart <= y.npart_cap, "run_akgm: partial buffer too small");
     p.partials = y.partials;
     launch_cgemm(p, TM, EPI_AKGM, st);
     y.npart = p.npart; finalize_stats(y, st);
@@ -395,7 +471,7 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         p.res = x.p; p.res_bstride = x.bstride(); p.res_ld = C;
         p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
         p.npart = p.tiles * p.rowtiles;
-        require(p.npart <= y.npart, "attention: partial buffer too small");
+        require(p.npart <= y.npart_cap, "attention: partial buffer too small");
         p.partials = y.partials;
         launch_cgemm(p, 128, EPI_STD, st);
         y.npart = p.npart; finalize_stats(y, st);
@@ -549,6 +625,8 @@ static void finalize_weights(ucdir_ctx* c) {
         } else if (d.kind == "down" || d.kind == "up") {
             w.conv = upload_conv(c->wpool, W_(c, d.name + ".conv.weight", (size_t)d.cout * d.cin * 9).data(),
                                  W_(c, d.name + ".conv.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cin, 3);
+            if (d.kind == "up") upload_upconv(c->wpool, w.conv, W_(c, d.name + ".conv.weight", (size_t)d.cout * d.cin * 9).data(),
+                                              W_(c, d.name + ".conv.bias", d.cout).data());
         } else {
             const std::string r = d.name + ".res_block.";
             w.block_index = nb++;
@@ -886,6 +964,7 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
     Act out = make_act(pool, B, Ho, Wo, cout);
     Act res; if (residual) res = act_from_nchw(pool, residual, B, cout, Ho, Wo, st, false);
     ConvW w = upload_conv(pool, w_host, bias_host, gamma_host, beta_host, cout, c0 + (x1 ? c1 : 0), ksize);
+    if (mode == COLS_UP && ksize == 3) upload_upconv(pool, w, w_host, bias_host);
     run_conv(w, a0, x1 ? &a1 : nullptr, out, mode, silu, residual ? &res : nullptr, true, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, cout, Ho, Wo);
     HIPC(hipGetLastError());

@@ -119,3 +119,28 @@ static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const flo
         }
     return P;
 }
+
+// Upsample(nearest x2) + conv3x3 as four parity classes of 2x2 convolutions on the low-res grid:
+//   out[2y+py][2x+px] = sum_{dy,dx in {0,1}} Wp[py][px][dy][dx] . in[y+py+dy-1][x+px+dx-1]
+// with Wp = sums of the original taps that land on the same source pixel:
+//   parity 0: dy=0 <- {k=0}, dy=1 <- {k=1,2};   parity 1: dy=0 <- {k=0,1}, dy=1 <- {k=2}.
+// Layout [4 parities][rows_pad][4*Cin], k = (dy*2+dx)*Cin + c.  (reference: model/ucdir.py:53-60)
+static inline PackedConv pack_upconv(const float* w, const float* bias, int cout, int cin, int TM) {
+    PackedConv P;
+    P.ntaps = 4; P.cin = cin; P.cout = cout; P.ncls = 1;
+    P.Kpad = 4 * cin;
+    P.rows_pad = ((cout + TM - 1) / TM) * TM;
+    P.A.assign((size_t)4 * P.rows_pad * P.Kpad, 0);
+    P.bias.assign(P.rows_pad, 0.f);
+    if (bias) for (int o = 0; o < cout; ++o) P.bias[o] = bias[o];
+    auto in_set = [](int par, int d, int k) { return par == 0 ? (d == 0 ? k == 0 : k >= 1) : (d == 0 ? k <= 1 : k == 2); };
+    for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px)
+        for (int o = 0; o < cout; ++o) for (int c = 0; c < cin; ++c)
+            for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+                double sum = 0;
+                for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+                    if (in_set(py, dy, ky) && in_set(px, dx, kx)) sum += w[((size_t)o * cin + c) * 9 + ky * 3 + kx];
+                P.A[((size_t)(py * 2 + px) * P.rows_pad + o) * P.Kpad + (size_t)(dy * 2 + dx) * cin + c] = f2bf((float)sum);
+            }
+    return P;
+}
