@@ -1,0 +1,254 @@
+// AKGM tail (GroupNorm2 -> grouped spdyconv -> per-pixel modulation sum -> swish -> + residual) for
+// C >= 128 (16 / 32 / 64 channels per group) on a 2-D pixel tile with an LDS halo (gfx950).
+// Reference: model/ucdir.py:129-140.
+//
+// Same structure as conv_halo.hip.h (512 threads, 16x16-style tile, 64-byte swizzled LDS rows, A
+// tiles of 128 rows x 64 k through a 2-deep ring, raw s_barrier), plus:
+//   * the K order of the packed weights makes every 16-wide MFMA k step one tap x 16 contiguous
+//     channels, so K is exact (144 / 288 / 576 per group: no padded taps on the matrix cores);
+//   * one workgroup stages the halo of its 32-channel chunk(s) ONCE and runs several "units" over
+//     it: the 2 groups of a chunk (cg = 16), or the 2 / 4 row tiles of a group (cg = 32 / 64);
+//   * per unit the 8 kernel sets of a feature sit in one lane's accumulators (row permutation of
+//     pack_akgm), the modulation sum happens in registers against a [9][128] fold table in LDS, and
+//     a 20 KB stage (aliasing the idle A ring) feeds the coalesced swish/residual/stats/store phase.
+#pragma once
+#include "conv_halo.hip.h"
+
+struct AkgmHP {
+    const bf16_t* A; int Kpad;                 // [8 groups][C rows][Kpad], K order see pack_akgm_halo
+    const bf16_t* h; long long h_bstride;      // swish(conv1), zero-bordered NHWC, C channels
+    int C, cg, H, W, Wp, th, tw, tiles_x, tiles_y, nbatch;
+    const double* stats; double inv_count;
+    const float* bias; const float* Tb; const float* Tg;   // [8C], [9][8C], [9][8C] original order
+    const float* G; long long g_bstride; const float* attw;
+    const bf16_t* res; long long res_bstride;
+    bf16_t* out; long long out_bstride;
+    float* partials; int npart;
+};
+
+#define AH_TM 128
+#define AH_ASTAGE (2 * AH_TM * 64)               // 16384: [2 halves of 32 k][128 rows][64 B]
+#define AH_SL 20                                 // floats per pixel in the output stage (16 features + pad)
+#define AH_LDS (2 * HC_HALO_BYTES + 2 * AH_ASTAGE + 128 + 9 * AH_TM * 4)
+
+__global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;
+    unsigned char* aring = smem + 2 * HC_HALO_BYTES;
+    float* stage = reinterpret_cast<float*>(aring);                  // aliases the A ring between units
+    float* scal = reinterpret_cast<float*>(smem + 2 * HC_HALO_BYTES + 2 * AH_ASTAGE);
+    float* tcs = scal + 32;                                          // [9][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wq = wave & 3, hh = lane >> 5;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int cg = p.cg;
+    const int nsec = (cg == 16) ? 4 : 8;          // work sections per pixel tile: chunk pairs or groups
+    const int sec = lid % nsec;
+    int tq = lid / nsec;
+    const int tx = tq % p.tiles_x; tq /= p.tiles_x;
+    const int ty = tq % p.tiles_y;
+    const int b = tq / p.tiles_y;
+    const int th = p.th, tw = p.tw, hw = tw + 2;
+    const int y0 = ty * th, x0 = tx * tw;
+    const int hcount = (th + 2) * hw;
+    const int nslots = th * tw;
+    const int nunits = (cg == 16) ? 2 : (cg == 32 ? 2 : 4);
+    const int nchunks = (cg == 64) ? 2 : 1;                 // halo chunks (32 channels each) this workgroup needs
+    const int chunk0 = (cg == 16) ? sec : (cg == 32 ? sec : 2 * sec);
+    const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift
+    const int spc = (cg == 16) ? 3 : 5;                     // A stages (64 k) per 32-channel period
+
+    float mean, rstd;
+    {
+        double m = p.stats[b * 2] * p.inv_count;
+        double var = p.stats[b * 2 + 1] * p.inv_count - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    const float mr = mean * rstd;
+
+    // ---- halo: stage chunk(s) once -----------------------------------------------------------------
+    {
+        const bf16_t* hb = p.h + (long long)b * p.h_bstride;
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int hp = (i * 8 + wave) * 16 + (lane >> 2);
+                if ((i * 8 + wave) * 16 < hcount) {
+                    if (hp < hcount) {
+                        const int hr = hp / hw, hc = hp - hr * hw;
+                        int gy = y0 + hr, gx = x0 + hc;
+                        gy = gy > p.H + 1 ? p.H + 1 : gy;
+                        gx = gx > p.W + 1 ? p.W + 1 : gx;
+                        const int j = (lane & 3) ^ ((hp >> 2) & 3);
+                        stage16(hb + (long long)(gy * p.Wp + gx) * p.C + (chunk0 + c) * 32 + j * 8,
+                                halo + c * HC_HALO_BYTES + (i * 8 + wave) * 1024, lane);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- per-lane pixel constants --------------------------------------------------------------------
+    int hp0[2], cls[2]; bool valid[2];
+    float att[2][8];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+        int slot = wq * 64 + tp * 32 + (lane & 31);
+        const bool inb = slot < nslots;
+        slot = inb ? slot : nslots - 1;
+        const int r = slot / tw, c = slot - r * tw;
+        hp0[tp] = r * hw + c;
+        int y = y0 + r, x = x0 + c;
+        valid[tp] = inb && y < p.H && x < p.W;
+        y = y < p.H ? y : p.H - 1; x = x < p.W ? x : p.W - 1;
+        cls[tp] = (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+        const float* gp = p.G + (long long)b * p.g_bstride + ((long long)y * p.W + x) * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+        const float* aw = p.attw + b * 8;
+        att[tp][0] = g0.x * aw[0]; att[tp][1] = g0.y * aw[1]; att[tp][2] = g0.z * aw[2]; att[tp][3] = g0.w * aw[3];
+        att[tp][4] = g1.x * aw[4]; att[tp][5] = g1.y * aw[5]; att[tp][6] = g1.z * aw[6]; att[tp][7] = g1.w * aw[7];
+    }
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int row = wm * 64 + tm * 32 + (lane & 31);
+        a_off[tm] = row * 64; a_sw[tm] = (row >> 2) & 3;
+    }
+    const int arow = wave * 16 + (lane >> 2);
+    const int ajsw = (lane & 3) ^ ((arow >> 2) & 3);
+
+    float s1 = 0.f, s2 = 0.f;
+    for (int unit = 0; unit < nunits; ++unit) {
+        int group, fbase, base16;
+        const bf16_t* Au;
+        if (cg == 16) { group = 2 * sec + unit; fbase = group * 16; base16 = unit * 2; Au = p.A + (long long)group * p.C * p.Kpad; }
+        else { group = sec; fbase = group * cg + unit * 16; base16 = 0; Au = p.A + ((long long)group * p.C + unit * AH_TM) * p.Kpad; }
+        const int nk = spc * nchunks;
+
+        __syncthreads();                        // previous unit's phase 2 done with stage / tcs
+        // fold table of this unit: Tc[cls][r] for original rows o = 8*fbase + r
+        for (int i = tid; i < 9 * AH_TM; i += HC_THREADS) {
+            const int cl = i / AH_TM, r = i - cl * AH_TM;
+            const int o = 8 * fbase + r;
+            tcs[i] = p.bias[o] + p.Tb[(long long)cl * 8 * p.C + o] - mr * p.Tg[(long long)cl * 8 * p.C + o];
+        }
+        auto issue_A = [&](int st, int slot) {
+            unsigned char* ab = aring + slot * AH_ASTAGE + wave * 1024;
+            const bf16_t* src = Au + (long long)arow * p.Kpad + st * 64 + ajsw * 8;
+            stage16(src, ab, lane);
+            stage16(src + 32, ab + AH_TM * 64, lane);
+        };
+        issue_A(0, 0);
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+
+        int cch = 0, sp = 0;                     // halo chunk and stage index within the chunk period
+        for (int s = 0; s < nk; ++s) {
+            HC_WAIT(0);
+            asm volatile("s_barrier" ::: "memory");
+            if (s + 1 < nk) issue_A(s + 1, (s + 1) & 1);
+            const unsigned char* Hb = halo + cch * HC_HALO_BYTES;
+            const unsigned char* Ab = aring + (s & 1) * AH_ASTAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k16 = sp * 4 + j;
+                const int tap = k16 >> tshift;
+                if (tap < 9) {
+                    const int ky = tap_ky(tap), kx = tap - 3 * ky;
+                    const int sh = ky * hw + kx;
+                    const int ch16 = base16 + ((k16 & tshift) << 1) + hh;      // 16-byte chunk inside the 64-byte halo row
+                    const int kch = (j & 1) * 2 + hh;                           // chunk inside the A half-stage row
+                    const unsigned char* Ah = Ab + (j >> 1) * (AH_TM * 64);
+                    bf16x8_t af[2], bfr[2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        af[tm] = *reinterpret_cast<const bf16x8_t*>(Ah + a_off[tm] + ((kch ^ a_sw[tm]) << 4));
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) {
+                        const int hp = hp0[tp] + sh;
+                        bfr[tp] = *reinterpret_cast<const bf16x8_t*>(Hb + hp * 64 + ((ch16 ^ ((hp >> 2) & 3)) << 4));
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tp = 0; tp < 2; ++tp)
+                            acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+                }
+            }
+            if (++sp == spc) { sp = 0; ++cch; }
+        }
+
+        // ---- phase 1: modulation sum in registers -> stage[px][16 features] (aliases the A ring) ---
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            const int px = wq * 64 + tp * 32 + (lane & 31);
+            const float* tc = tcs + cls[tp] * AH_TM;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int t32 = wm * 2 + tm;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int floc = 4 * t32 + 2 * q + hh;
+                    const float4 c0 = *reinterpret_cast<const float4*>(tc + 8 * floc);
+                    const float4 c1 = *reinterpret_cast<const float4*>(tc + 8 * floc + 4);
+                    const float tcv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    float sa = 0.f, sb = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) { sa += att[tp][s] * acc[tm][tp][8 * q + s]; sb += att[tp][s] * tcv[s]; }
+                    stage[px * AH_SL + floc] = valid[tp] ? (rstd * sa + sb) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: one (pixel, 8 features) item per thread ----------------------------------------
+        {
+            const int px = tid >> 1, f8 = (tid & 1) * 8;
+            if (px < nslots) {
+                const int r = px / tw, c = px - r * tw;
+                const int y = y0 + r, x = x0 + c;
+                if (y < p.H && x < p.W) {
+                    const long long off = ((long long)(y + 1) * p.Wp + (x + 1)) * p.C + fbase + f8;
+                    const float4 a = *reinterpret_cast<const float4*>(&stage[px * AH_SL + f8]);
+                    const float4 d = *reinterpret_cast<const float4*>(&stage[px * AH_SL + f8 + 4]);
+                    const float v0[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+                    const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + off);
+                    const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
+                    uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = silu_fast(v0[i]) + bf2f(rh[i]);
+                        s1 += v; s2 += v * v;
+                        oh[i] = f2bf(v);
+                    }
+                    *reinterpret_cast<uint4*>(p.out + (long long)b * p.out_bstride + off) = ov;
+                }
+            }
+        }
+    }
+    if (p.partials) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        __syncthreads();
+        if (lane == 0) { scal[2 + wave * 2] = s1; scal[3 + wave * 2] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2 += scal[3 + w * 2]; }
+            float* pp = p.partials + ((long long)b * p.npart + (long long)(ty * p.tiles_x + tx) * nsec + sec) * 2;
+            pp[0] = t1; pp[1] = t2;
+        }
+    }
+}

@@ -14,6 +14,7 @@
 #include "cgemm.hip.h"
 #include "akgm64.hip.h"
 #include "conv_halo.hip.h"
+#include "akgm_halo.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -358,12 +359,50 @@ static void run_akgm64(const AkgmW& w, const Act& h1, const float* G, const floa
     y.npart = p.npart; finalize_stats(y, st);
 }
 
+// C >= 128: halo-tile AKGM kernel (akgm_halo.hip.h)
+static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
+        attr_done = true;
+    }
+    AkgmHP p;
+    p.A = w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
+    p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
+    choose_tile(y.H, y.W, p.th, p.tw);
+    p.tiles_x = (y.W + p.tw - 1) / p.tw; p.tiles_y = (y.H + p.th - 1) / p.th; p.nbatch = y.B;
+    p.stats = h1.stats; p.inv_count = 1.0 / ((double)w.C * h1.H * h1.W);
+    p.bias = w.bias; p.Tb = w.Tb; p.Tg = w.Tg;
+    p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
+    p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
+    const int nsec = (w.cg == 16) ? 4 : 8;
+    p.npart = p.tiles_x * p.tiles_y * nsec;
+    require(p.npart <= y.npart_cap, "run_akgm_halo: partial buffer too small");
+    p.partials = y.partials;
+    const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
+    if (g_prof.on) {
+        ProfEntry e; e.key = 111; e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
+        e.e0 = g_prof.get(); e.e1 = g_prof.get();
+        HIPC(hipEventRecord(e.e0, st));
+        hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        HIPC(hipEventRecord(e.e1, st));
+        g_prof.entries.push_back(e);
+    } else {
+        hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+    }
+    HIPC(hipGetLastError());
+    y.npart = p.npart; finalize_stats(y, st);
+}
+
 // AKGM tail of a block: y = swish(sum_s spdyconv(GN2(h1))[c,s] * G[s] * attw[s]) + res
 static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y,
                      hipStream_t st) {
     const int C = w.C;
     require(C == 64 || C % 128 == 0, "AKGM: channel count must be 64 or a multiple of 128");
     if (C == 64) { run_akgm64(w, h1, G, attw, res, y, st); return; }
+    if (g_use_halo && (w.cg == 16 || w.cg == 32 || w.cg == 64)) { run_akgm_halo(w, h1, G, attw, res, y, st); return; }
+    require(w.Kpad != 640, "AKGM weights packed for the halo kernel");
     GemmP p; zero_gemm(p);
     const int TM = (C == 64) ? 64 : 128;
     p.A = w.A; p.a_ld = w.Kpad; p.a_rows = C; p.a_gstride = (long long)C * w.Kpad;

@@ -86,7 +86,10 @@ static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const flo
     PackedAkgm P;
     P.C = C; P.cg = C / 8;
     const int cg = P.cg;
-    P.Kpad = kpad_override ? kpad_override : ((9 * cg + 63) / 64) * 64;
+    // cg == 64 (akgm_halo): K is ordered [32-channel chunk][tap][32] with each chunk padded to 320, so
+    // that every 64-k A stage belongs to one halo chunk; otherwise k = tap*cg + ci.
+    const bool chunked = (cg == 64) && !kpad_override;
+    P.Kpad = kpad_override ? kpad_override : (chunked ? 640 : ((9 * cg + 63) / 64) * 64);
     P.A.assign((size_t)8 * C * P.Kpad, 0);
     P.bias.assign((size_t)8 * C, 0.f);
     P.Tb.assign((size_t)9 * 8 * C, 0.f);
@@ -105,7 +108,7 @@ static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const flo
                 for (int t = 0; t < 9; ++t) {
                     const float wv = wsp[((size_t)o * cg + ci) * 9 + t];
                     const bf16_t q = f2bf(wv * gamma[cglob]);
-                    row[(size_t)t * cg + ci] = q;
+                    row[chunked ? (size_t)(ci / 32) * 320 + (size_t)t * 32 + (ci % 32) : (size_t)t * cg + ci] = q;
                     wb[t] += (double)wv * beta[cglob];
                     wg[t] += (double)bf2f(q);
                 }
