@@ -113,6 +113,18 @@ int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double
 /* algorithmic FLOPs of one forward at the prepared shape (2*MAC, reference op count) */
 double  ucdir_forward_flops(const ucdir_ctx* ctx);
 
+/* ---- UNetSeeInDark predictor (model/ucdir.py:310-416): initial restoration = guide = residual base.
+ * `name` = reference state_dict key without the "predictor." prefix ("conv1_1.weight", "upv6.bias", ...).
+ * forward: x (B,3,H,W) fp32 -> y (B,3,H,W) fp32, same +32 reflect pad / crop as the reference. */
+typedef struct ucdir_predictor ucdir_predictor;
+int32_t ucdir_predictor_create(int32_t device, ucdir_predictor** out);
+void    ucdir_predictor_destroy(ucdir_predictor* p);
+int32_t ucdir_predictor_load_weight(ucdir_predictor* p, const char* name, const float* data_host,
+                                    const int64_t* shape, int32_t ndim);
+int32_t ucdir_predictor_finalize(ucdir_predictor* p);
+int32_t ucdir_predictor_forward(ucdir_predictor* p, const float* x, float* y, int32_t B, int32_t H, int32_t W,
+                                void* stream);
+
 /* ---- single-operator entry points (unit parity tests; fp32 NCHW in/out, bf16 inside) -----
  * conv: y = act(conv(GN?(cat[x0,x1]))) with 3x3 (mode 0 stride 1, 1 stride-2 down,
  * 2 nearest-x2-up then 3x3) or 1x1 (ksize 1).  gamma/beta NULL = no GroupNorm fold. */

@@ -192,6 +192,18 @@ def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=N
     return out, eps.cpu(), ref
 
 
+def predictor_case(B, H, W, seed=3, net_sd=None):
+    """UNetSeeInDark on the HIP engine vs the oracle (model/ucdir.py:352-403)."""
+    net, sd = net_sd if net_sd is not None else build_net(UNetConfig(inner_channel=64, channel_mults=(1, 2), res_blocks=1,
+                                                                    attn_res=(64,), image_size=128))
+    x = torch.from_numpy(synth_inputs(B, H, W, seed=seed)[0])
+    ref = O.predictor_forward(sd, x)
+    with torch.no_grad():
+        got = net.predictor(x.to(DEV))
+    torch.cuda.synchronize()
+    return metrics(got, ref)
+
+
 def sampler_step_case(seed=0):
     from ucdir_amd.ucdir import sampler_step_
     g = rng(seed)

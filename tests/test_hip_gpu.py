@@ -57,6 +57,12 @@ def test_attention(shape):
     assert not m["nan"] and m["rel_rms_branch"] < 1.2e-2, m
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 256), (1, 40, 72)])
+def test_predictor(shape):
+    m = C.predictor_case(*shape)
+    assert not m["nan"] and m["rel_rms"] < 1.5e-2, m
+
+
 def test_sampler_step_exact():
     for k, m in C.sampler_step_case().items():
         assert m["max_abs"] < 2e-6, (k, m)       # fp32 point-wise; differences are FMA contraction only

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int cg = p.cg;
-    const int nsec = (cg == 16) ? 4 : 8;          // work sections per pixel tile: chunk pairs or groups
+    const int nsec = (cg == 8) ? p.C / 32 : ((cg == 16) ? 4 : 8);   // work sections per pixel tile: 32-channel chunks or groups
     const int sec = lid % nsec;
     int tq = lid / nsec;
     const int tx = tq % p.tiles_x; tq /= p.tiles_x;
@@ -58,11 +58,11 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     const int y0 = ty * th, x0 = tx * tw;
     const int hcount = (th + 2) * hw;
     const int nslots = th * tw;
-    const int nunits = (cg == 16) ? 2 : (cg == 32 ? 2 : 4);
+    const int nunits = (cg == 64) ? 4 : 2;
     const int nchunks = (cg == 64) ? 2 : 1;                 // halo chunks (32 channels each) this workgroup needs
-    const int chunk0 = (cg == 16) ? sec : (cg == 32 ? sec : 2 * sec);
-    const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift
-    const int spc = (cg == 16) ? 3 : 5;                     // A stages (64 k) per 32-channel period
+    const int chunk0 = (cg == 64) ? 2 * sec : sec;
+    const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift   (cg >= 16)
+    const int spc = (cg == 8) ? 2 : ((cg == 16) ? 3 : 5);   // A stages (64 k) per 32-channel period
 
     float mean, rstd;
     {
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     for (int unit = 0; unit < nunits; ++unit) {
         int group, fbase, base16;
         const bf16_t* Au;
-        if (cg == 16) { group = 2 * sec + unit; fbase = group * 16; base16 = unit * 2; Au = p.A + (long long)group * p.C * p.Kpad; }
+        if (cg == 8) {       // unit = two adjacent groups (64 rows each): row half wm belongs to group 4*sec + 2*unit + wm
+            group = 4 * sec + 2 * unit; fbase = group * 8; base16 = 2 * unit + wm; Au = p.A + (long long)group * 64 * p.Kpad;
+        } else if (cg == 16) { group = 2 * sec + unit; fbase = group * 16; base16 = unit * 2; Au = p.A + (long long)group * p.C * p.Kpad; }
         else { group = sec; fbase = group * cg + unit * 16; base16 = 0; Au = p.A + ((long long)group * p.C + unit * AH_TM) * p.Kpad; }
         const int nk = spc * nchunks;
 
@@ -164,11 +166,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k16 = sp * 4 + j;
-                const int tap = k16 >> tshift;
+                // cg == 8: one k16 step = taps 2*k16 (lanes 0-31) and 2*k16+1 (lanes 32-63) x 8 channels
+                int tap = (cg == 8) ? 2 * k16 : (k16 >> tshift);
                 if (tap < 9) {
+                    if (cg == 8) { tap += hh; tap = tap > 8 ? 8 : tap; }       // tap 9 has zero weights
                     const int ky = tap_ky(tap), kx = tap - 3 * ky;
                     const int sh = ky * hw + kx;
-                    const int ch16 = base16 + ((k16 & tshift) << 1) + hh;      // 16-byte chunk inside the 64-byte halo row
+                    const int ch16 = (cg == 8) ? base16 : base16 + ((k16 & tshift) << 1) + hh;   // 16-byte chunk inside the 64-byte halo row
                     const int kch = (j & 1) * 2 + hh;                           // chunk inside the A half-stage row
                     const unsigned char* Ah = Ab + (j >> 1) * (AH_TM * 64);
                     bf16x8_t af[2], bfr[2];

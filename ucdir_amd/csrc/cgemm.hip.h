@@ -355,7 +355,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         }
         if (p.act) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = (p.act == 1) ? silu_f(v[i]) : fmaxf(0.2f * v[i], v[i]);
         }
         if (p.res) {
             const bf16_t* rp = p.res + (long long)b * p.res_bstride + (long long)cp * p.res_ld + p.res_coff + f;
@@ -366,7 +366,16 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
-        if (p.out_nchw) {
+        if (p.shuffle_c) {
+            const int q = f / p.shuffle_c, o = f - q * p.shuffle_c;
+            const int y = cp / p.Wp - 1, x = cp - (y + 1) * p.Wp - 1;
+            const long long op2 = (long long)(2 * y + (q >> 1) + 1) * (2 * p.W + 2) + (2 * x + (q & 1) + 1);
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + op2 * p.out_ld + p.out_coff + o;
+            uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) oh[i] = f2bf(v[i]);
+            *reinterpret_cast<uint4*>(op) = ov;
+        } else if (p.out_nchw) {
             const int y = cp / p.Wp - 1, x = cp - (y + 1) * p.Wp - 1;
             if (y < p.crop_h && x < p.crop_w) {
                 float* op = reinterpret_cast<float*>(p.out) + (((long long)b * p.nfeat + f) * p.crop_h + y) * p.crop_w + x;

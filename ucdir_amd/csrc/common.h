@@ -23,7 +23,11 @@ __host__ __device__ inline float bf2f(bf16_t h) {
 
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // swish with v_rcp_f32 instead of an IEEE divide (1 ulp; the result is rounded to bf16 anyway)
+// act codes of the epilogues: 0 none, 1 swish, 2 LeakyReLU(0.2) as max(0.2x, x) (model/ucdir.py:414-416)
+__device__ inline float act_apply(float v, int act);
 __device__ inline float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+__device__ inline float act_apply(float v, int act) { return act == 1 ? silu_fast(v) : (act == 2 ? fmaxf(0.2f * v, v) : v); }
 
 // Activation tensor in HBM: zero-bordered NHWC bf16, [B][H+2][W+2][C].  The one-pixel zero
 // border makes every 3x3 tap of an interior pixel an in-bounds read of the right value, so the
@@ -70,6 +74,7 @@ struct GemmP {
     const bf16_t* res; long long res_bstride; int res_ld; int res_coff;
     void* out; long long out_bstride; int out_ld; int out_coff; int out_f32; int out_compact;
     int out_nchw; int crop_h, crop_w;   // final conv: fp32 NCHW (B, nfeat, crop_h, crop_w)
+    int shuffle_c;                      // > 0: ConvTranspose2d(2,2): feature f = q*shuffle_c + o goes to pixel (2y+q/2, 2x+q%2), channel o
     int nfeat;               // valid output features (rows) in total
     float* partials; int npart;
     // AKGM

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             }
             if (p.act) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+                for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], p.act);
             }
             if (p.res) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);

@@ -12,7 +12,6 @@
 
 #include "../../include/ucdir_hip.h"
 #include "cgemm.hip.h"
-#include "akgm64.hip.h"
 #include "conv_halo.hip.h"
 #include "akgm_halo.hip.h"
 #include "common.h"
@@ -91,7 +90,7 @@ static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* 
     W.Aup = pool.upload(P.A); W.Kup = P.Kpad;
 }
 static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
-    PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, C == 64 ? 80 : 0);   // C == 64: dedicated kernel, exact K
+    PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, 0);
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
@@ -324,42 +323,7 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
 }
 
-// C == 64 (full-resolution level): dedicated halo-tile kernel (akgm64.hip.h)
-static float* g_tc64 = nullptr; static size_t g_tc64_cap = 0;
-static void run_akgm64(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)akgm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A64_LDS));
-        attr_done = true;
-    }
-    const size_t need = (size_t)y.B * 9 * 512 * sizeof(float);
-    if (need > g_tc64_cap) { if (g_tc64) (void)hipFree(g_tc64); HIPC(hipMalloc((void**)&g_tc64, need)); g_tc64_cap = need; }
-    const double inv = 1.0 / (64.0 * h1.H * h1.W);
-    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv, w.bias, w.Tb, w.Tg, 512, g_tc64);
-    Akgm64P p;
-    p.A = w.A; p.h = h1.p; p.h_bstride = h1.bstride();
-    p.H = y.H; p.W = y.W; p.Wp = y.W + 2; p.p0 = p.Wp + 1; p.pn = (y.H - 1) * p.Wp + y.W;
-    p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.nbatch = y.B;
-    p.stats = h1.stats; p.inv_count = inv; p.Tc = g_tc64;
-    p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
-    p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
-    p.npart = p.tiles; require(p.npart <= y.npart_cap, "run_akgm64: partial buffer too small");
-    p.partials = y.partials;
-    if (g_prof.on) {
-        ProfEntry e; e.key = 11; e.flops = 2.0 * 9 * 64 * 64 * (double)y.H * y.W * y.B;
-        e.bytes = (3.0 * 64 * 2 + 32) * (double)y.H * y.W * y.B; e.e0 = g_prof.get(); e.e1 = g_prof.get();
-        HIPC(hipEventRecord(e.e0, st));
-        hipLaunchKernelGGL(akgm64_kernel, dim3(y.B * p.tiles), dim3(CG_THREADS), A64_LDS, st, p);
-        HIPC(hipEventRecord(e.e1, st));
-        g_prof.entries.push_back(e);
-    } else {
-        hipLaunchKernelGGL(akgm64_kernel, dim3(y.B * p.tiles), dim3(CG_THREADS), A64_LDS, st, p);
-    }
-    HIPC(hipGetLastError());
-    y.npart = p.npart; finalize_stats(y, st);
-}
-
-// C >= 128: halo-tile AKGM kernel (akgm_halo.hip.h)
+// halo-tile AKGM kernel (akgm_halo.hip.h): 8 / 16 / 32 / 64 channels per group
 static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -375,7 +339,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.bias = w.bias; p.Tb = w.Tb; p.Tg = w.Tg;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
-    const int nsec = (w.cg == 16) ? 4 : 8;
+    const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
     p.npart = p.tiles_x * p.tiles_y * nsec;
     require(p.npart <= y.npart_cap, "run_akgm_halo: partial buffer too small");
     p.partials = y.partials;
@@ -400,8 +364,7 @@ static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float*
                      hipStream_t st) {
     const int C = w.C;
     require(C == 64 || C % 128 == 0, "AKGM: channel count must be 64 or a multiple of 128");
-    if (C == 64) { run_akgm64(w, h1, G, attw, res, y, st); return; }
-    if (g_use_halo && (w.cg == 16 || w.cg == 32 || w.cg == 64)) { run_akgm_halo(w, h1, G, attw, res, y, st); return; }
+    if (g_use_halo && (w.cg == 8 || w.cg == 16 || w.cg == 32 || w.cg == 64)) { run_akgm_halo(w, h1, G, attw, res, y, st); return; }
     require(w.Kpad != 640, "AKGM weights packed for the halo kernel");
     GemmP p; zero_gemm(p);
     const int TM = (C == 64) ? 64 : 128;
@@ -788,7 +751,7 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         if (d.kind == "stem") {
             dim3 grid((c->Hc * c->Wc + 255) / 256, d.cout / 64, B);
             r.out.npart = (int)(grid.x * grid.y);
-            hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, cond, xt, c->H, c->W, c->Hc, c->Wc, d.cout, w.stem_w,
+            hipLaunchKernelGGL((stem_kernel<6, 0>), grid, dim3(256), 0, st, cond, xt, c->H, c->W, c->Hc, c->Wc, d.cout, w.stem_w,
                                w.stem_b, r.out.p, r.out.partials, r.out.npart);
             HIPC(hipGetLastError());
             finalize_stats(r.out, st);
@@ -1050,6 +1013,226 @@ int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int3
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(st));
+    API_END
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// UNetSeeInDark predictor on the same kernels (reference: model/ucdir.py:310-416).
+// 32-channel layers are carried as 64 channels with a zero upper half (zero weights / bias), so
+// every conv runs on conv3x3_halo; ConvTranspose2d(2,2) is a 1x1 GEMM with a pixel-shuffle store.
+// ================================================================================================
+struct PredConv { ConvW w; int cin_real, cout_real; };
+
+struct ucdir_predictor {
+    int device = 0;
+    std::map<std::string, HostT> host;
+    bool finalized = false;
+    DevPool wpool, apool;
+    float* in_w = nullptr; float* in_b = nullptr;            // conv1_1 (3 -> 32, VALU kernel), padded to 64 outputs
+    std::map<std::string, ConvW> conv;                       // conv{l}_{1,2}, upv{l}, conv10_1
+    int B = 0, H = 0, W = 0, Hc = 0, Wc = 0;
+    std::map<std::string, Act> act;
+};
+
+static int pad64(int c) { return c < 64 ? 64 : c; }
+
+// weights [cout][cin][k][k] -> zero-padded [pad64(cout)][sum of padded sources][k][k]; `splits` lists the real
+// channel counts of the concatenated sources (each padded to >= 64 separately)
+static std::vector<float> pad_conv_weight(const std::vector<float>& w, int cout, std::vector<int> splits, int kk, int& cin_pad, int& cout_pad) {
+    int cin = 0; for (int s : splits) cin += s;
+    cin_pad = 0; for (int s : splits) cin_pad += pad64(s);
+    cout_pad = pad64(cout);
+    std::vector<float> o((size_t)cout_pad * cin_pad * kk, 0.f);
+    for (int oc = 0; oc < cout; ++oc) {
+        int src = 0, dst = 0;
+        for (int s : splits) {
+            for (int c = 0; c < s; ++c)
+                for (int k = 0; k < kk; ++k) o[((size_t)oc * cin_pad + dst + c) * kk + k] = w[((size_t)oc * cin + src + c) * kk + k];
+            src += s; dst += pad64(s);
+        }
+    }
+    return o;
+}
+static std::vector<float> pad_bias(const std::vector<float>& b, int cout_pad) {
+    std::vector<float> o(cout_pad, 0.f);
+    for (size_t i = 0; i < b.size(); ++i) o[i] = b[i];
+    return o;
+}
+
+static void predictor_finalize(ucdir_predictor* c) {
+    c->wpool.release(); c->conv.clear();
+    auto H_ = [&](const std::string& n) -> const std::vector<float>& {
+        auto it = c->host.find(n); require(it != c->host.end(), "predictor: missing weight " + n); return it->second.v; };
+    // conv1_1: 3 -> 32 on the VALU input kernel, weights [27][64]
+    {
+        const auto& w = H_("conv1_1.weight"); const auto& b = H_("conv1_1.bias");
+        require(w.size() == 32 * 3 * 9, "predictor: conv1_1.weight size");
+        std::vector<float> t((size_t)27 * 64, 0.f);
+        for (int o = 0; o < 32; ++o) for (int ci = 0; ci < 3; ++ci) for (int k = 0; k < 9; ++k)
+            t[(size_t)(k * 3 + ci) * 64 + o] = w[((size_t)o * 3 + ci) * 9 + k];
+        c->in_w = c->wpool.upload(t); c->in_b = c->wpool.upload(pad_bias(b, 64));
+    }
+    struct Spec { const char* name; int cout; std::vector<int> splits; };
+    const std::vector<Spec> specs = {
+        {"conv1_2", 32, {32}}, {"conv2_1", 64, {32}}, {"conv2_2", 64, {64}}, {"conv3_1", 128, {64}}, {"conv3_2", 128, {128}},
+        {"conv4_1", 256, {128}}, {"conv4_2", 256, {256}}, {"conv5_1", 512, {256}}, {"conv5_2", 512, {512}},
+        {"conv6_1", 256, {256, 256}}, {"conv6_2", 256, {256}}, {"conv7_1", 128, {128, 128}}, {"conv7_2", 128, {128}},
+        {"conv8_1", 64, {64, 64}}, {"conv8_2", 64, {64}}, {"conv9_1", 32, {32, 32}}, {"conv9_2", 32, {32}}};
+    for (const auto& sp : specs) {
+        int cinp, coutp;
+        auto wp = pad_conv_weight(H_(std::string(sp.name) + ".weight"), sp.cout, sp.splits, 9, cinp, coutp);
+        auto bp = pad_bias(H_(std::string(sp.name) + ".bias"), coutp);
+        c->conv[sp.name] = upload_conv(c->wpool, wp.data(), bp.data(), nullptr, nullptr, coutp, cinp, 3);
+    }
+    {   // conv10_1: 1x1 32 -> 3
+        int cinp, coutp;
+        auto wp = pad_conv_weight(H_("conv10_1.weight"), 3, {32}, 1, cinp, coutp);
+        std::vector<float> w3((size_t)3 * cinp); for (int o = 0; o < 3; ++o) for (int ci = 0; ci < cinp; ++ci) w3[(size_t)o * cinp + ci] = wp[(size_t)o * cinp + ci];
+        c->conv["conv10_1"] = upload_conv(c->wpool, w3.data(), H_("conv10_1.bias").data(), nullptr, nullptr, 3, cinp, 1);
+    }
+    // ConvTranspose2d(cin, cout, 2, stride 2): weight [cin][cout][2][2] -> 1x1 GEMM rows r = q*coutp + o
+    const int ups[4][3] = {{6, 512, 256}, {7, 256, 128}, {8, 128, 64}, {9, 64, 32}};
+    for (auto& u : ups) {
+        const std::string n = "upv" + std::to_string(u[0]);
+        const int cin = u[1], cout = u[2], coutp = pad64(cout);
+        const auto& w = H_(n + ".weight"); const auto& b = H_(n + ".bias");
+        require(w.size() == (size_t)cin * cout * 4, "predictor: " + n + " size");
+        std::vector<float> t((size_t)4 * coutp * cin, 0.f), bb((size_t)4 * coutp, 0.f);
+        for (int q = 0; q < 4; ++q) for (int o = 0; o < cout; ++o) {
+            bb[(size_t)q * coutp + o] = b[o];
+            for (int ci = 0; ci < cin; ++ci) t[((size_t)q * coutp + o) * cin + ci] = w[((size_t)ci * cout + o) * 4 + q];
+        }
+        c->conv[n] = upload_conv(c->wpool, t.data(), bb.data(), nullptr, nullptr, 4 * coutp, cin, 1);
+    }
+    c->host.clear();
+    c->finalized = true;
+}
+
+static void predictor_plan(ucdir_predictor* c, int B, int H, int W) {
+    c->apool.release(); c->act.clear();
+    c->B = B; c->H = H; c->W = W; c->Hc = (H / 32 + 1) * 32; c->Wc = (W / 32 + 1) * 32;
+    require(H >= 33 && W >= 33, "predictor: H, W must be >= 33 (reflect pad)");
+    const int ch[5] = {64, 64, 128, 256, 512};
+    for (int l = 0; l < 5; ++l) {
+        const int h = c->Hc >> l, w = c->Wc >> l;
+        const std::string L = std::to_string(l + 1);
+        c->act["a" + L] = make_act(c->apool, B, h, w, ch[l], false);      // conv{l}_1 output
+        c->act["c" + L] = make_act(c->apool, B, h, w, ch[l], false);      // conv{l}_2 output (skip)
+        if (l < 4) c->act["p" + L] = make_act(c->apool, B, h / 2, w / 2, ch[l], false);
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int h = c->Hc >> l, w = c->Wc >> l;
+        const std::string L = std::to_string(9 - l);                     // 6..9
+        c->act["u" + L] = make_act(c->apool, B, h, w, ch[l], false);      // upv output
+        c->act["a" + L] = make_act(c->apool, B, h, w, ch[l], false);
+        c->act["c" + L] = make_act(c->apool, B, h, w, ch[l], false);
+    }
+}
+
+static void predictor_forward(ucdir_predictor* c, const float* x, float* y, hipStream_t st) {
+    const int B = c->B;
+    auto A = [&](const std::string& n) -> Act& { return c->act.at(n); };
+    auto CV = [&](const std::string& n) -> const ConvW& { return c->conv.at(n); };
+    {   // conv1_1 + LeakyReLU, reading NCHW fp32 with the bottom/right reflect pad (model/ucdir.py:354-361)
+        dim3 grid((c->Hc * c->Wc + 255) / 256, 1, B);
+        hipLaunchKernelGGL((stem_kernel<3, 2>), grid, dim3(256), 0, st, x, x, c->H, c->W, c->Hc, c->Wc, 64, c->in_w, c->in_b,
+                           A("a1").p, (float*)nullptr, 0);
+        HIPC(hipGetLastError());
+    }
+    run_conv(CV("conv1_2"), A("a1"), nullptr, A("c1"), COLS_S1, 2, nullptr, false, st);
+    for (int l = 1; l <= 4; ++l) {
+        const std::string L = std::to_string(l), N = std::to_string(l + 1);
+        Act& src = A("c" + L); Act& dst = A("p" + L);
+        hipLaunchKernelGGL(maxpool2_kernel, dim3(2048), dim3(256), 0, st, src.p, dst.p, B, src.H, src.W, src.C);
+        HIPC(hipGetLastError());
+        run_conv(CV("conv" + N + "_1"), dst, nullptr, A("a" + N), COLS_S1, 2, nullptr, false, st);
+        run_conv(CV("conv" + N + "_2"), A("a" + N), nullptr, A("c" + N), COLS_S1, 2, nullptr, false, st);
+    }
+    const Act* cur = &A("c5");
+    for (int l = 6; l <= 9; ++l) {
+        const std::string L = std::to_string(l);
+        Act& up = A("u" + L);
+        const ConvW& w = CV("upv" + L);
+        {   // ConvTranspose2d(2,2): 1x1 GEMM over the low-res grid, pixel-shuffle store into `up`
+            GemmP p; zero_gemm(p);
+            p.A = w.A; p.a_ld = w.Kpad; p.a_rows = w.rows_pad;
+            p.B0 = cur->p; p.b0_bstride = cur->bstride(); p.ld0 = cur->C; p.c0 = cur->C;
+            p.cols_mode = COLS_S1; p.H = cur->H; p.W = cur->W; p.Wp = cur->W + 2; p.Hi = cur->H; p.Wi = cur->W; p.Wpi = p.Wp;
+            p.p0 = p.Wp + 1; p.pn = (cur->H - 1) * p.Wp + cur->W;
+            p.ntaps = 1; p.cg = cur->C; p.cpt = cur->C / 8; p.nk = w.Kpad / CG_BK;
+            p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = w.rows_pad / w.TM; p.nbatch = B;
+            p.bias = w.bias; p.nfeat = w.cout; p.shuffle_c = up.C;
+            p.out = up.p; p.out_bstride = up.bstride(); p.out_ld = up.C;
+            launch_cgemm(p, w.TM, EPI_STD, st);
+        }
+        const Act& skip = A("c" + std::to_string(10 - l));
+        run_conv(CV("conv" + L + "_1"), up, &skip, A("a" + L), COLS_S1, 2, nullptr, false, st);
+        run_conv(CV("conv" + L + "_2"), A("a" + L), nullptr, A("c" + L), COLS_S1, 2, nullptr, false, st);
+        cur = &A("c" + L);
+    }
+    {   // conv10_1 (1x1, 32 -> 3), fp32 NCHW cropped to H x W
+        const ConvW& w = CV("conv10_1");
+        GemmP p; zero_gemm(p);
+        p.A = w.A; p.a_ld = w.Kpad; p.a_rows = w.rows_pad;
+        p.B0 = cur->p; p.b0_bstride = cur->bstride(); p.ld0 = cur->C; p.c0 = cur->C;
+        p.cols_mode = COLS_S1; p.H = cur->H; p.W = cur->W; p.Wp = cur->W + 2; p.Hi = cur->H; p.Wi = cur->W; p.Wpi = p.Wp;
+        p.p0 = p.Wp + 1; p.pn = (cur->H - 1) * p.Wp + cur->W;
+        p.ntaps = 1; p.cg = cur->C; p.cpt = cur->C / 8; p.nk = w.Kpad / CG_BK;
+        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = w.rows_pad / w.TM; p.nbatch = B;
+        p.bias = w.bias; p.nfeat = 3; p.out = y; p.out_nchw = 1; p.crop_h = c->H; p.crop_w = c->W;
+        launch_cgemm(p, w.TM, EPI_STD, st);
+    }
+}
+
+extern "C" {
+
+int32_t ucdir_predictor_create(int32_t device, ucdir_predictor** out) {
+    API_BEGIN
+    require(out, "null argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    require(e == hipSuccess && ndev > 0, "no HIP device available (libucdir_hip has no CPU fallback)");
+    HIPC(hipSetDevice(device));
+    std::unique_ptr<ucdir_predictor> c(new ucdir_predictor());
+    c->device = device;
+    *out = c.release();
+    API_END
+}
+void ucdir_predictor_destroy(ucdir_predictor* p) { delete p; }
+
+int32_t ucdir_predictor_load_weight(ucdir_predictor* p, const char* name, const float* data_host, const int64_t* shape, int32_t ndim) {
+    API_BEGIN
+    require(p && name && data_host && shape, "null argument");
+    HostT t; size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.v.assign(data_host, data_host + n);
+    p->host[name] = std::move(t);
+    p->finalized = false;
+    API_END
+}
+
+int32_t ucdir_predictor_finalize(ucdir_predictor* p) {
+    API_BEGIN
+    require(p, "null argument");
+    HIPC(hipSetDevice(p->device));
+    predictor_finalize(p);
+    HIPC(hipDeviceSynchronize());
+    API_END
+}
+
+int32_t ucdir_predictor_forward(ucdir_predictor* p, const float* x, float* y, int32_t B, int32_t H, int32_t W, void* stream) {
+    API_BEGIN
+    require(p && x && y, "null argument");
+    require(p->finalized, "predictor weights not finalized");
+    hipStream_t st = (hipStream_t)stream;
+    if (B != p->B || H != p->H || W != p->W) {
+        HIPC(hipStreamSynchronize(st));
+        predictor_plan(p, B, H, W);
+        HIPC(hipDeviceSynchronize());
+    }
+    predictor_forward(p, x, y, st);
     API_END
 }
 

@@ -87,15 +87,17 @@ __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 
 // zero-bordered NHWC bf16 activation + GroupNorm partial sums.  K = 54: VALU, not MFMA.
 // grid (ceil(Hc*Wc/256), C0/64, B), block 256; w: [54][C0] fp32 (k = (ky*3+kx)*6 + ci)
 // ------------------------------------------------------------------------------------------------
+// CIN = 6: DY3h stem (cat[cond, x_t]); CIN = 3: first conv of the predictor (xt unused, LeakyReLU)
+template <int CIN, int ACT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cond, const float* __restrict__ xt,
                                                    int H, int W, int Hc, int Wc, int C0,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    bf16_t* __restrict__ out, float* __restrict__ partials, int npart) {
-    __shared__ __attribute__((aligned(16))) float ws[54 * 64];
+    __shared__ __attribute__((aligned(16))) float ws[9 * CIN * 64];
     __shared__ float red[8];
     const int cb = blockIdx.y * 64;
     const int b = blockIdx.z;
-    for (int i = threadIdx.x; i < 54 * 64; i += 256) ws[i] = w[(i / 64) * C0 + cb + (i % 64)];
+    for (int i = threadIdx.x; i < 9 * CIN * 64; i += 256) ws[i] = w[(i / 64) * C0 + cb + (i % 64)];
     __syncthreads();
     const int pix = blockIdx.x * 256 + threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
@@ -113,10 +115,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ con
                 if (xx < 0 || xx >= Wc) continue;
                 const int xs = reflect_idx(xx, W);
 #pragma unroll
-                for (int ci = 0; ci < 6; ++ci) {
+                for (int ci = 0; ci < CIN; ++ci) {
                     const float* src = ci < 3 ? cond : xt;
                     const float v = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
-                    const float* wr = ws + ((ky * 3 + kx) * 6 + ci) * 64;
+                    const float* wr = ws + ((ky * 3 + kx) * CIN + ci) * 64;
 #pragma unroll
                     for (int c = 0; c < 64; c += 4) {
                         const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
@@ -130,7 +132,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ con
         for (int c = 0; c < 64; c += 8) {
             uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { oh[k] = f2bf(acc[c + k]); s1 += acc[c + k]; s2 += acc[c + k] * acc[c + k]; }
+            for (int k = 0; k < 8; ++k) {
+                const float a = (ACT == 2) ? fmaxf(0.2f * acc[c + k], acc[c + k]) : acc[c + k];
+                oh[k] = f2bf(a); s1 += a; s2 += a * a;
+            }
             *reinterpret_cast<uint4*>(op + c) = ov;
         }
     }
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ con
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && partials) {
         float* pp = partials + ((long long)b * npart + (long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
         pp[0] = red[0] + red[2] + red[4] + red[6];
         pp[1] = red[1] + red[3] + red[5] + red[7];
@@ -347,5 +352,35 @@ __global__ void sampler_step_kernel(float* __restrict__ xt, const float* __restr
         float r = coef1 * x0 + coef2 * x;
         if (noise) r += noise[i] * sigma;
         xt[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 max pooling (predictor, model/ucdir.py:317,363): zero-bordered NHWC bf16 in and out.
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
+    const long long n = (long long)B * Ho * Wo * c8n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8; long long t = i / c8n;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho); const int b = (int)(t / Ho);
+        const bf16_t* base = x + (((long long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C + c;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const uint4 v = *reinterpret_cast<const uint4*>(base + ((long long)dy * (W + 2) + dx) * C);
+                const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], bf2f(h[k]));
+            }
+        uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) oh[k] = f2bf(m[k]);
+        *reinterpret_cast<uint4*>(y + (((long long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C + c) = ov;
     }
 }

@@ -44,6 +44,11 @@ _SIGS = {
     "ucdir_profile_read": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), POINTER(c_double),
                                      POINTER(c_double), POINTER(c_int32), c_void_p]),
     "ucdir_forward_flops": (c_double, [c_void_p]),
+    "ucdir_predictor_create": (c_int32, [c_int32, POINTER(c_void_p)]),
+    "ucdir_predictor_destroy": (None, [c_void_p]),
+    "ucdir_predictor_load_weight": (c_int32, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]),
+    "ucdir_predictor_finalize": (c_int32, [c_void_p]),
+    "ucdir_predictor_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "ucdir_op_conv": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),

@@ -196,10 +196,13 @@ def sampler_step_(x_t, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma):
 
 
 class UNetSeeInDark(nn.Module):
-    """Initial-restoration predictor (model/ucdir.py:310-416); parameter names match the reference."""
+    """Initial-restoration predictor (model/ucdir.py:310-416) on the HIP engine; parameter names and
+    shapes match the reference, there is no PyTorch forward."""
 
     def __init__(self, in_channels=3, out_channels=3):
         super().__init__()
+        if in_channels != 3 or out_channels != 3:
+            raise NotImplementedError("the UCDIR predictor is 3 -> 3 channels")
         for name, shape in predictor_param_shapes(in_channels, out_channels).items():
             t = torch.empty(shape)
             if name.endswith("weight"):
@@ -207,26 +210,46 @@ class UNetSeeInDark(nn.Module):
             else:
                 nn.init.uniform_(t, -0.05, 0.05)
             _attach(self, name, nn.Parameter(t))
+        self._h = None
+        self._wkey = None
 
-    def _c3(self, t, n):
-        m = self._modules[n]
-        t = F.conv2d(t, m.weight, m.bias, padding=1)
-        return torch.max(0.2 * t, t)
+    def _handle(self):
+        L = _lib.load()
+        if self._h is None:
+            p = next(self.parameters())
+            if p.device.type != "cuda":
+                raise _lib.UcdirError("UNetSeeInDark runs only on an MI355X (move the module to 'cuda'); there is no CPU path")
+            dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
+            h = ctypes.c_void_p()
+            _lib.check(L.ucdir_predictor_create(dev, ctypes.byref(h)))
+            self._h = h
+        return self._h
+
+    def _sync_weights(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key == self._wkey:
+            return
+        L = _lib.load()
+        h = self._handle()
+        for name, p in self.named_parameters():
+            a = np.ascontiguousarray(p.detach().float().cpu().numpy())
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            _lib.check(L.ucdir_predictor_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
+        _lib.check(L.ucdir_predictor_finalize(h))
+        self._wkey = key
 
     def forward(self, x):
-        _, _, h, w = x.shape
-        ph, pw = (h // 32 + 1) * 32 - h, (w // 32 + 1) * 32 - w
-        t = F.pad(x, (0, pw, 0, ph), mode="reflect")
-        enc = []
-        for lvl in range(1, 5):
-            t = self._c3(self._c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
-            enc.append(t)
-            t = F.max_pool2d(t, 2)
-        t = self._c3(self._c3(t, "conv5_1"), "conv5_2")
-        for lvl in range(6, 10):
-            up = self._modules[f"upv{lvl}"]
-            t = F.conv_transpose2d(t, up.weight, up.bias, stride=2)
-            t = torch.cat([t, enc.pop()], dim=1)
-            t = self._c3(self._c3(t, f"conv{lvl}_1"), f"conv{lvl}_2")
-        last = self._modules["conv10_1"]
-        return F.conv2d(t, last.weight, last.bias)[..., :-ph, :-pw]
+        L = _lib.load()
+        self._sync_weights()
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        y = torch.empty_like(x)
+        _lib.check(L.ucdir_predictor_forward(self._handle(), _ptr(x), _ptr(y), B, H, W, _stream_ptr()))
+        return y
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().ucdir_predictor_destroy(self._h)
+        except Exception:
+            pass
