@@ -62,7 +62,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     constexpr int KBUF = cgemm_kbuf_bytes<TM>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: no waterfall loops around global_load_lds
     const int wm = wave >> 1, wp = wave & 1;
 
     // ---- XCD-aware workgroup -> (batch, column tile, row tile) mapping ----------------------

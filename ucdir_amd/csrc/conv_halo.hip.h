@@ -72,7 +72,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     float* stage = reinterpret_cast<float*>(smem);
     constexpr int SL = TM + 4;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: no waterfall loops around global_load_lds
     const int wm = wave / NPG, wq = wave % NPG;
     int lid;
     {

@@ -307,7 +307,14 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     HIPC(hipMemset(dbgbuf, 0, 256 * 8));
     p.dbg = dbgbuf;
 #endif
-    if (halo) { if (w.TM == 128) launch_halo<128>(p, st); else launch_halo<64>(p, st); }
+    int tm_run = w.TM;
+    if (halo && tm_run == 128 && p.nbatch * p.tiles * p.rowtiles < 256) {
+        // too few workgroups for 256 CUs x 2: use 64-row tiles (the packed [rows][K] layout is the same)
+        tm_run = 64; p.rowtiles = w.rows_pad / 64;
+        if (want_stats) { p.npart = p.tiles * p.rowtiles; require(p.npart <= y.npart_cap, "run_conv: partial buffer too small"); }
+    }
+    if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else launch_halo<64>(p, st); }
+    else launch_cgemm(p, w.TM, EPI_STD, st);
 #ifdef UCDIR_TIMING
     if (halo) {
         unsigned long long h[256];
@@ -319,7 +326,6 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         fprintf(stderr, "\n");
     }
 #endif
-    else launch_cgemm(p, w.TM, EPI_STD, st);
     if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
 }
 
