@@ -25,10 +25,11 @@ def bench_name(k):
     if m:
         tm, epi, mode = int(m.group(1)), int(m.group(2)), int(m.group(3))
         return f"cgemm<{tm},akgm>" if epi == 1 else f"cgemm<{tm},std,{MODE[mode]}>"
-    if k.startswith("akgm64_kernel"):
-        return "akgm64_halo"
-    if k.startswith("conv3x3_halo"):
-        return "conv3x3_halo"
+    if k.startswith("akgm_halo_kernel"):
+        return "akgm_halo"
+    m = re.search(r"conv3x3_halo_kernel<(\d+)>", k)
+    if m:
+        return f"conv3x3_halo<{m.group(1)}>"      # also carries the parity-decomposed Upsample launches
     return None
 
 
