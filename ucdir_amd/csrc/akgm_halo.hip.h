@@ -19,17 +19,30 @@ struct AkgmHP {
     const bf16_t* h; long long h_bstride;      // swish(conv1), zero-bordered NHWC, C channels
     int C, cg, H, W, Wp, th, tw, tiles_x, tiles_y, nbatch;
     const double* stats; double inv_count;
-    const float* bias; const float* Tb; const float* Tg;   // [8C], [9][8C], [9][8C] original order
+    const float* Tc;                           // [B][9][8C]: bias + Tb - mean*rstd*Tg (akgm_tc_kernel), original row order
     const float* G; long long g_bstride; const float* attw;
     const bf16_t* res; long long res_bstride;
     bf16_t* out; long long out_bstride;
     float* partials; int npart;
+    unsigned long long* dbg;
 };
 
 #define AH_TM 128
 #define AH_ASTAGE (2 * AH_TM * 64)               // 16384: [2 halves of 32 k][128 rows][64 B]
 #define AH_SL 20                                 // floats per pixel in the output stage (16 features + pad)
 #define AH_LDS (2 * HC_HALO_BYTES + 2 * AH_ASTAGE + 128 + 9 * AH_TM * 4)
+
+// Tc[b][cls][o] = bias[o] + Tb[cls][o] - mean_b * rstd_b * Tg[cls][o]   (once per launch; grid (9, B))
+__global__ void akgm_tc_kernel(const double* __restrict__ stats, double inv_count, const float* __restrict__ bias,
+                               const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc) {
+    const int b = blockIdx.y, cls = blockIdx.x;
+    double m = stats[b * 2] * inv_count;
+    double var = stats[b * 2 + 1] * inv_count - m * m;
+    if (var < 0) var = 0;
+    const float mr = (float)m * (float)(1.0 / sqrt(var + 1e-5));
+    for (int o = threadIdx.x; o < n; o += blockDim.x)
+        Tc[((long long)b * 9 + cls) * n + o] = bias[o] + Tb[(long long)cls * n + o] - mr * Tg[(long long)cls * n + o];
+}
 
 __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,14 +78,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift   (cg >= 16)
     const int spc = (cg == 8) ? 2 : ((cg == 16) ? 3 : 5);   // A stages (64 k) per 32-channel period
 
-    float mean, rstd;
+    float rstd;
     {
         double m = p.stats[b * 2] * p.inv_count;
         double var = p.stats[b * 2 + 1] * p.inv_count - m * m;
         if (var < 0) var = 0;
-        mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
+        rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
-    const float mr = mean * rstd;
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
     {
@@ -125,6 +137,14 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     const int arow = wave * 16 + (lane >> 2);
     const int ajsw = (lane & 3) ^ ((arow >> 2) & 3);
 
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
+    int dbg_n = 0;
+#define AH_STAMP() do { if (dbg_on) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AH_STAMP() do {} while (0)
+#endif
+    AH_STAMP();
     float s1 = 0.f, s2 = 0.f;
     for (int unit = 0; unit < nunits; ++unit) {
         int group, fbase, base16;
@@ -136,11 +156,14 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         const int nk = spc * nchunks;
 
         __syncthreads();                        // previous unit's phase 2 done with stage / tcs
-        // fold table of this unit: Tc[cls][r] for original rows o = 8*fbase + r
-        for (int i = tid; i < 9 * AH_TM; i += HC_THREADS) {
-            const int cl = i / AH_TM, r = i - cl * AH_TM;
-            const int o = 8 * fbase + r;
-            tcs[i] = p.bias[o] + p.Tb[(long long)cl * 8 * p.C + o] - mr * p.Tg[(long long)cl * 8 * p.C + o];
+        // fold table slice of this unit, Tc[b][cls][8*fbase .. +128), DMA'd into LDS next to the first A stage:
+        // instruction w (waves 0-4) carries classes 2w and 2w+1 (32 lanes x 16 B each)
+        if (wave < 5) {
+            const int cl = 2 * wave + (lane >> 5);
+            if (cl < 9)
+                __builtin_amdgcn_global_load_lds(
+                    (const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + cl) * 8 * p.C + 8 * fbase + (lane & 31) * 4),
+                    (LDS_AS void*)(reinterpret_cast<unsigned char*>(tcs) + wave * 1024), 16, 0, 0);
         }
         auto issue_A = [&](int st, int slot) {
             unsigned char* ab = aring + slot * AH_ASTAGE + wave * 1024;
@@ -148,6 +171,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
             stage16(src, ab, lane);
             stage16(src + 32, ab + AH_TM * 64, lane);
         };
+        AH_STAMP();
         issue_A(0, 0);
         f32x16_t acc[2][2];
 #pragma unroll
@@ -195,6 +219,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
             if (++sp == spc) { sp = 0; ++cch; }
         }
 
+        AH_STAMP();
         // ---- phase 1: modulation sum in registers -> stage[px][16 features] (aliases the A ring) ---
         __syncthreads();
 #pragma unroll
@@ -218,6 +243,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
             }
         }
         __syncthreads();
+        AH_STAMP();
         // ---- phase 2: one (pixel, 8 features) item per thread ----------------------------------------
         {
             const int px = tid >> 1, f8 = (tid & 1) * 8;
@@ -243,6 +269,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
             }
         }
     }
+    AH_STAMP();
+#ifdef UCDIR_TIMING
+    if (dbg_on) p.dbg[255] = dbg_n;
+#endif
     if (p.partials) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }

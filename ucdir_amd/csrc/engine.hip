@@ -336,13 +336,18 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
         HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
         attr_done = true;
     }
+    static float* tcbuf = nullptr; static size_t tccap = 0;
+    const size_t need = (size_t)y.B * 9 * 8 * w.C * sizeof(float);
+    if (need > tccap) { if (tcbuf) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tcbuf); } HIPC(hipMalloc((void**)&tcbuf, need)); tccap = need; }
+    const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
+    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf);
     AkgmHP p;
     p.A = w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
     p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
     choose_tile(y.H, y.W, p.th, p.tw);
     p.tiles_x = (y.W + p.tw - 1) / p.tw; p.tiles_y = (y.H + p.th - 1) / p.th; p.nbatch = y.B;
     p.stats = h1.stats; p.inv_count = 1.0 / ((double)w.C * h1.H * h1.W);
-    p.bias = w.bias; p.Tb = w.Tb; p.Tg = w.Tg;
+    p.Tc = tcbuf;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
     const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
@@ -350,6 +355,23 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     require(p.npart <= y.npart_cap, "run_akgm_halo: partial buffer too small");
     p.partials = y.partials;
     const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
+    p.dbg = nullptr;
+#ifdef UCDIR_TIMING
+    static unsigned long long* dbgbuf = nullptr;
+    if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
+    HIPC(hipMemset(dbgbuf, 0, 256 * 8));
+    p.dbg = dbgbuf;
+    hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+    {
+        unsigned long long h[256];
+        HIPC(hipStreamSynchronize(st));
+        HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
+        const int n = (int)h[255];
+        fprintf(stderr, "AKGM TIMING cg=%d n=%d:", w.cg, n);
+        for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (g_prof.on) {
         ProfEntry e; e.key = 111; e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
