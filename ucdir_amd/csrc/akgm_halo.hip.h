@@ -257,14 +257,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
                     const float v0[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
                     const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + off);
                     const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
-                    uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+                    float vv[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float v = silu_fast(v0[i]) + bf2f(rh[i]);
-                        s1 += v; s2 += v * v;
-                        oh[i] = f2bf(v);
+                        vv[i] = silu_fast(v0[i]) + bf2f(rh[i]);
+                        s1 += vv[i]; s2 += vv[i] * vv[i];
                     }
-                    *reinterpret_cast<uint4*>(p.out + (long long)b * p.out_bstride + off) = ov;
+                    *reinterpret_cast<uint4*>(p.out + (long long)b * p.out_bstride + off) = pack8_bf16(vv);
                 }
             }
         }

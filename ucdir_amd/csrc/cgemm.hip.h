@@ -371,10 +371,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             const int y = cp / p.Wp - 1, x = cp - (y + 1) * p.Wp - 1;
             const long long op2 = (long long)(2 * y + (q >> 1) + 1) * (2 * p.W + 2) + (2 * x + (q & 1) + 1);
             bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + op2 * p.out_ld + p.out_coff + o;
-            uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) oh[i] = f2bf(v[i]);
-            *reinterpret_cast<uint4*>(op) = ov;
+            *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
         } else if (p.out_nchw) {
             const int y = cp / p.Wp - 1, x = cp - (y + 1) * p.Wp - 1;
             if (y < p.crop_h && x < p.crop_w) {
@@ -389,11 +386,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
             bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + opos * p.out_ld + p.out_coff + f;
-            uint4 ov;
-            bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) oh[i] = f2bf(v[i]);
-            *reinterpret_cast<uint4*>(op) = ov;
+            *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
         }
     }
     if (p.partials) {

@@ -21,6 +21,16 @@ __host__ __device__ inline float bf2f(bf16_t h) {
     return v.f;
 }
 
+// two fp32 -> packed bf16x2 in one instruction (round-to-nearest-even, same result as f2bf)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint4 pack8_bf16(const float* v) {
+    return make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+}
+
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // swish with v_rcp_f32 instead of an IEEE divide (1 ulp; the result is rounded to bf16 anyway)
 // act codes of the epilogues: 0 none, 1 swish, 2 LeakyReLU(0.2) as max(0.2x, x) (model/ucdir.py:414-416)

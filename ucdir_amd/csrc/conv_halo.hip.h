@@ -319,10 +319,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                         if (f + i < p.nfeat) op[(long long)i * p.crop_h * p.crop_w] = v[i];
                 }
             } else {
-                uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) oh[i] = f2bf(v[i]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = ov;
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = pack8_bf16(v);
             }
         }
     }

@@ -475,7 +475,10 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
     // 4. P = softmax_j(S)
     {
         const long long rows = (long long)B * N;
-        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.S, a.P, rows, N, Npad);
+        const dim3 g((unsigned)((rows + 3) / 4));
+        if (Npad <= 64 * 4 * 2) hipLaunchKernelGGL((softmax_kernel<2>), g, dim3(256), 0, st, a.S, a.P, rows, N, Npad);
+        else if (Npad <= 64 * 4 * 6) hipLaunchKernelGGL((softmax_kernel<6>), g, dim3(256), 0, st, a.S, a.P, rows, N, Npad);
+        else hipLaunchKernelGGL((softmax_kernel<0>), g, dim3(256), 0, st, a.S, a.P, rows, N, Npad);
     }
     // 5. O[i][c] = sum_j P[i][j] V[c][j]   (rows = channels, cols = queries, K = Npad)
     {

@@ -180,13 +180,10 @@ __global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__
         const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+        float fv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float f = (bf2f(h[k]) - mean) * rstd * gg[k] + bb[k];
-            oh[k] = f2bf(silu_f(f));
-        }
-        *reinterpret_cast<uint4*>(y + off) = ov;
+        for (int k = 0; k < 8; ++k) fv[k] = silu_fast((bf2f(h[k]) - mean) * rstd * gg[k] + bb[k]);
+        *reinterpret_cast<uint4*>(y + off) = pack8_bf16(fv);
     }
 }
 
@@ -303,8 +300,11 @@ __global__ __launch_bounds__(256) void guide_branch_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // row softmax: S fp32 [B][N][Npad] -> P bf16 [B][N][Npad] (columns >= N written as 0).
-// One wave per row, three streaming passes (rows are L2 resident).
+// One wave per row.  Rows up to 64*4*NV floats are read ONCE with 16-byte loads and kept in
+// registers (max, exp, sum, normalise, 8-byte bf16 stores); longer rows (1024^2 patch windows,
+// N = 16384) stream three times from L2.
 // ------------------------------------------------------------------------------------------------
+template <int NV>   // float4 vectors per lane held in registers
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
                                                       long long rows, int N, int Npad) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -312,14 +312,47 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const float* s = S + row * Npad;
     bf16_t* pr = P + row * Npad;
-    float m = -3.0e38f;
-    for (int j = lane; j < N; j += 64) m = fmaxf(m, s[j]);
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    float sum = 0.f;
-    for (int j = lane; j < N; j += 64) sum += expf(s[j] - m);
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < Npad; j += 64) pr[j] = j < N ? f2bf(expf(s[j] - m) * inv) : (bf16_t)0;
+    if (NV > 0) {
+        float4 v[NV > 0 ? NV : 1];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = (i * 64 + lane) * 4;
+            if (j < Npad) v[i] = *reinterpret_cast<const float4*>(s + j); else v[i] = make_float4(0, 0, 0, 0);
+            if (j + 0 < N) m = fmaxf(m, v[i].x);
+            if (j + 1 < N) m = fmaxf(m, v[i].y);
+            if (j + 2 < N) m = fmaxf(m, v[i].z);
+            if (j + 3 < N) m = fmaxf(m, v[i].w);
+        }
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = (i * 64 + lane) * 4;
+            v[i].x = j + 0 < N ? expf(v[i].x - m) : 0.f;
+            v[i].y = j + 1 < N ? expf(v[i].y - m) : 0.f;
+            v[i].z = j + 2 < N ? expf(v[i].z - m) : 0.f;
+            v[i].w = j + 3 < N ? expf(v[i].w - m) : 0.f;
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = (i * 64 + lane) * 4;
+            if (j < Npad)
+                *reinterpret_cast<uint2*>(pr + j) = make_uint2(pack2_bf16(v[i].x * inv, v[i].y * inv), pack2_bf16(v[i].z * inv, v[i].w * inv));
+        }
+    } else {
+        float m = -3.0e38f;
+        for (int j = lane; j < N; j += 64) m = fmaxf(m, s[j]);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float sum = 0.f;
+        for (int j = lane; j < N; j += 64) sum += expf(s[j] - m);
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < Npad; j += 64) pr[j] = j < N ? f2bf(expf(s[j] - m) * inv) : (bf16_t)0;
+    }
 }
 
 // V^T: QKV compact [B][N][ld] (v at channel offset voff) -> [B][C][Npad] bf16
