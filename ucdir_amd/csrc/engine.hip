@@ -256,7 +256,7 @@ static bool g_use_halo = true;
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
 static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
-                     bool want_stats, hipStream_t st) {
+                     bool want_stats, hipStream_t st, float* nchw_out = nullptr, int crop_h = 0, int crop_w = 0) {
     GemmP p; zero_gemm(p);
     const int cin = x0.C + (x1 ? x1->C : 0);
     require(cin == w.cin, "run_conv: channel mismatch");
@@ -282,6 +282,7 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     p.bias = w.bias;
     if (res) { p.res = res->p; p.res_bstride = res->bstride(); p.res_ld = res->C; p.res_coff = 0; }
     p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = y.C; p.nfeat = w.cout;
+    if (nchw_out) { p.out = nchw_out; p.out_nchw = 1; p.crop_h = crop_h; p.crop_w = crop_w; }   // fp32 (B, cout, crop_h, crop_w)
     const bool upph = g_use_halo && mode == COLS_UP && w.Aup && x0.C % 64 == 0 && !x1;
     const bool halo = upph || (g_use_halo && mode == COLS_S1 && w.ntaps == 9 && x0.C % 64 == 0 && (!x1 || x1->C % 64 == 0));
     if (halo) {
@@ -810,18 +811,8 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         hipLaunchKernelGGL(gn_silu_kernel, dim3(2048, 1, B), dim3(256), 0, st, cur->p, c->fin_act.p, c->Hc, c->Wc, C,
                            cur->stats, 1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta);
         HIPC(hipGetLastError());
-        const ConvW& w = c->fin_conv;
-        const Act& x0 = c->fin_act;
-        GemmP p; zero_gemm(p);
-        p.A = w.A; p.a_ld = w.Kpad; p.a_rows = w.rows_pad;
-        p.B0 = x0.p; p.b0_bstride = x0.bstride(); p.ld0 = C; p.c0 = C;
-        p.cols_mode = COLS_S1; p.H = x0.H; p.W = x0.W; p.Wp = x0.W + 2; p.Hi = x0.H; p.Wi = x0.W; p.Wpi = p.Wp;
-        p.p0 = p.Wp + 1; p.pn = (x0.H - 1) * p.Wp + x0.W;
-        p.ntaps = 9; p.cg = C; p.cpt = C / 8; p.nk = w.Kpad / CG_BK;
-        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = w.rows_pad / w.TM; p.nbatch = B;
-        p.bias = w.bias; p.nfeat = w.cout;
-        p.out = eps; p.out_nchw = 1; p.crop_h = c->H; p.crop_w = c->W;
-        launch_cgemm(p, w.TM, EPI_STD, st);
+        Act dummy; dummy.B = B; dummy.H = c->Hc; dummy.W = c->Wc; dummy.C = c->fin_conv.cout;
+        run_conv(c->fin_conv, c->fin_act, nullptr, dummy, COLS_S1, 0, nullptr, false, st, eps, c->H, c->W);
     }
 }
 
