@@ -8,7 +8,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libucdir_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["cgemm.hip.h", "misc.hip.h", "pack.h", "common.h", os.path.join("..", "..", "include", "ucdir_hip.h")]
+
+
+def _deps():
+    """Every file the translation unit can include: all of csrc/ plus the public header."""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+    out.append(os.path.join(HERE, "..", "include", "ucdir_hip.h"))
+    return out
 
 
 def _hipcc():
@@ -22,8 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
+    for p in _deps():
         if os.path.exists(p) and os.path.getmtime(p) > t:
             return True
     return False

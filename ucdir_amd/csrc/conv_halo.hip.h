@@ -29,7 +29,7 @@
 // per-workgroup GroupNorm-fold table Tc[9][TM].  <= 80 KB so two workgroups share a CU: one
 // workgroup's prologue / epilogue overlaps the other's matrix-core loop.
 template <int TM>
-__host__ __device__ constexpr int hc_kloop_bytes() { return 2 * HC_HALO_BYTES + 2 * 2 * TM * HC_BK * 2; }
+__host__ __device__ constexpr int hc_kloop_bytes() { return 2 * HC_HALO_BYTES + 2 * (256 / TM) * TM * HC_BK * 2; }   // taps/step = 256/TM: 16 KB stage
 template <int TM>
 __host__ __device__ constexpr int hc_stage_bytes() { return ((TM == 128) ? 128 : 256) * (TM + 4) * 4; }
 template <int TM>
@@ -65,6 +65,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     constexpr int TPW = 256 / NPG;            // pixels per wave (64 | 32)
     constexpr int NTP = TPW / 32;             // 32-pixel MFMA tiles per wave (2 | 1)
     constexpr int PXH = (TM == 128) ? 128 : 256;   // pixels per epilogue pass
+    constexpr int TPS = 256 / TM;             // taps per K step (2 | 4): 16 MFMAs per wave between barriers
+    constexpr int ASTAGE = TPS * TM * HC_BK * 2;  // 16384
     unsigned char* halo = smem;
     unsigned char* aring = smem + 2 * HC_HALO_BYTES;
     float* scal = reinterpret_cast<float*>(smem + hc_scal_off<TM>());
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     const int nchunks = p.cg / HC_BK;
     const int nh_min = ((hcount + 15) / 16) / 8;    // halo staging instructions every wave issues (some issue one more)
     const int ntap = p.up_phase ? 4 : 9;
-    const int nsteps_c = (ntap + 1) >> 1;          // steps (tap pairs) per chunk
+    const int nsteps_c = (ntap + TPS - 1) / TPS;   // steps per chunk
     const int nk = nchunks * nsteps_c;
     auto issue_halo = [&](int c, int buf) {
         int ch = c * HC_BK;
@@ -148,20 +150,27 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             }
         }
     };
-    // ---- weight tile loader: TM rows x 64 B; 16 rows per instruction, one instruction per wave ---
-    // (TM == 64: waves 4-7 re-stage rows 0-63 with identical data so every wave issues the same count)
-    int arow_off;
-    {
-        const int row = ((wave * 16) % TM) + (lane >> 2);
+    // ---- weight tile loader: a stage holds TPS taps x TM rows x 64 B = 16 KB = 16 wave instructions, two per wave:
+    // instruction k = 2*wave + j stages rows (k % (TM/16))*16 .. +15 of tap k / (TM/16)
+    int arow_off[2], atap[2], adst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 2 * wave + j;
+        const int row = (k % (TM / 16)) * 16 + (lane >> 2);
         const int ajsw = (lane & 3) ^ ((row >> 2) & 3);
-        arow_off = (rowtile * TM + row) * p.a_ld + ajsw * 8;
+        atap[j] = k / (TM / 16);
+        arow_off[j] = (rowtile * TM + row) * p.a_ld + ajsw * 8;
+        adst[j] = atap[j] * (TM * 64) + (k % (TM / 16)) * 1024;
     }
     const bf16_t* Abase = p.A + (long long)par * p.a_gstride;
-    auto issue_A = [&](int c, int u, int slot) {      // taps 2u and 2u+1 (the odd tail re-stages tap 2u: uniform count)
-        unsigned char* ab = aring + slot * (2 * TM * HC_BK * 2) + ((wave * 16) % TM) * 64;
-        const int t0 = 2 * u, t1 = (2 * u + 1 < ntap) ? 2 * u + 1 : 2 * u;
-        stage16(Abase + t0 * p.cg + c * HC_BK + arow_off, ab, lane);
-        stage16(Abase + t1 * p.cg + c * HC_BK + arow_off, ab + TM * HC_BK * 2, lane);
+    auto issue_A = [&](int c, int u, int slot) {      // taps TPS*u .. TPS*u+TPS-1 (tail taps re-stage the last valid one)
+        unsigned char* ab = aring + slot * ASTAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int t = TPS * u + atap[j];
+            t = t < ntap ? t : ntap - 1;
+            stage16(Abase + t * p.cg + c * HC_BK + arow_off[j], ab + adst[j], lane);
+        }
     };
 
     // ---- fragment geometry -----------------------------------------------------------------------
@@ -211,10 +220,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         HC_STAMP(3);
         const unsigned char* Hb = halo + (c & 1) * HC_HALO_BYTES;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int t = 2 * u + tt;
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int t = TPS * u + tt;
             if (t < ntap) {
-                const unsigned char* Ab = aring + (s & 1) * (2 * TM * HC_BK * 2) + tt * (TM * HC_BK * 2);
+                const unsigned char* Ab = aring + (s & 1) * ASTAGE + tt * (TM * HC_BK * 2);
                 int sh;
                 if (p.up_phase) sh = (py + (t >> 1)) * hw + (pxp + (t & 1));
                 else { const int ky = tap_ky(t); sh = ky * hw + (t - 3 * ky); }
