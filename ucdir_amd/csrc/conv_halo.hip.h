@@ -219,6 +219,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         if (u == 0 && c + 1 < nchunks) issue_halo(c + 1, (c + 1) & 1);
         HC_STAMP(3);
         const unsigned char* Hb = halo + (c & 1) * HC_HALO_BYTES;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
             const int t = TPS * u + tt;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 #ifdef UCDIR_TIMING
         asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NTP - 1][15]));
 #endif
