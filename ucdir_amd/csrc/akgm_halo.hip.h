@@ -48,7 +48,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
     unsigned char* aring = smem + 2 * HC_HALO_BYTES;
-    float* stage = reinterpret_cast<float*>(aring);                  // cg == 64: aliases the A ring between units
+    float* stage = reinterpret_cast<float*>(aring);                  // aliases the A ring between units
     float* scal = reinterpret_cast<float*>(smem + 2 * HC_HALO_BYTES + 2 * AH_ASTAGE);
     float* tcs = scal + 32;                                          // [9][128]
 
@@ -145,19 +145,19 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 #define AH_STAMP() do {} while (0)
 #endif
     AH_STAMP();
-    // cg < 64 leaves the second halo buffer free: the output stage lives there, so the weight ring is never
-    // aliased and weight stages / fold-table slices are prefetched ACROSS unit boundaries (no exposed DMA
-    // latency at the start of a unit).  cg == 64 needs both halo buffers; its stage aliases the idle ring.
-    const bool xpf = cg < 64;
-    if (xpf) stage = reinterpret_cast<float*>(halo + HC_HALO_BYTES);
-    auto unit_desc = [&](int unit, int& fbase, int& base16, const bf16_t*& Au) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int unit = 0; unit < nunits; ++unit) {
+        int group, fbase, base16;
+        const bf16_t* Au;
         if (cg == 8) {       // unit = two adjacent groups (64 rows each): row half wm belongs to group 4*sec + 2*unit + wm
-            const int group = 4 * sec + 2 * unit; fbase = group * 8; base16 = 2 * unit + wm; Au = p.A + (long long)group * 64 * p.Kpad;
-        } else if (cg == 16) { const int group = 2 * sec + unit; fbase = group * 16; base16 = unit * 2; Au = p.A + (long long)group * p.C * p.Kpad; }
-        else { fbase = sec * cg + unit * 16; base16 = 0; Au = p.A + ((long long)sec * p.C + unit * AH_TM) * p.Kpad; }
-    };
-    // fold table slice Tc[b][cls][8*fbase .. +128) -> LDS: instruction w (waves 0-4) carries classes 2w, 2w+1
-    auto issue_tc = [&](int fbase) {
+            group = 4 * sec + 2 * unit; fbase = group * 8; base16 = 2 * unit + wm; Au = p.A + (long long)group * 64 * p.Kpad;
+        } else if (cg == 16) { group = 2 * sec + unit; fbase = group * 16; base16 = unit * 2; Au = p.A + (long long)group * p.C * p.Kpad; }
+        else { group = sec; fbase = group * cg + unit * 16; base16 = 0; Au = p.A + ((long long)group * p.C + unit * AH_TM) * p.Kpad; }
+        const int nk = spc * nchunks;
+
+        __syncthreads();                        // previous unit's phase 2 done with stage / tcs
+        // fold table slice of this unit, Tc[b][cls][8*fbase .. +128), DMA'd into LDS next to the first A stage:
+        // instruction w (waves 0-4) carries classes 2w and 2w+1 (32 lanes x 16 B each)
         if (wave < 5) {
             const int cl = 2 * wave + (lane >> 5);
             if (cl < 9)
@@ -165,32 +165,14 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
                     (const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + cl) * 8 * p.C + 8 * fbase + (lane & 31) * 4),
                     (LDS_AS void*)(reinterpret_cast<unsigned char*>(tcs) + wave * 1024), 16, 0, 0);
         }
-    };
-    auto issue_A = [&](const bf16_t* Au, int st, int slot) {
-        unsigned char* ab = aring + slot * AH_ASTAGE + wave * 1024;
-        const bf16_t* src = Au + (long long)arow * p.Kpad + st * 64 + ajsw * 8;
-        stage16(src, ab, lane);
-        stage16(src + 32, ab + AH_TM * 64, lane);
-    };
-    const int nk = spc * nchunks;
-    int gs = 0;                                  // global K-step counter: ring slot = gs & 1
-    {
-        int fb0, b16; const bf16_t* A0;
-        unit_desc(0, fb0, b16, A0);
-        issue_tc(fb0);
-        issue_A(A0, 0, 0);
-    }
-    float s1 = 0.f, s2 = 0.f;
-    for (int unit = 0; unit < nunits; ++unit) {
-        int fbase, base16; const bf16_t* Au;
-        unit_desc(unit, fbase, base16, Au);
-        const bool has_next = unit + 1 < nunits;
-        if (!xpf && unit > 0) {
-            __syncthreads();                    // previous unit's phase 2 done with the stage that aliases the ring
-            issue_tc(fbase);
-            issue_A(Au, 0, gs & 1);
-        }
+        auto issue_A = [&](int st, int slot) {
+            unsigned char* ab = aring + slot * AH_ASTAGE + wave * 1024;
+            const bf16_t* src = Au + (long long)arow * p.Kpad + st * 64 + ajsw * 8;
+            stage16(src, ab, lane);
+            stage16(src + 32, ab + AH_TM * 64, lane);
+        };
         AH_STAMP();
+        issue_A(0, 0);
         f32x16_t acc[2][2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -200,17 +182,12 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
                 for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
 
         int cch = 0, sp = 0;                     // halo chunk and stage index within the chunk period
-        for (int s = 0; s < nk; ++s, ++gs) {
+        for (int s = 0; s < nk; ++s) {
             HC_WAIT(0);
             asm volatile("s_barrier" ::: "memory");
-            if (s + 1 < nk) issue_A(Au, s + 1, (gs + 1) & 1);
-            else if (xpf && has_next) {                                      // first stage of the next unit
-                int fn, bn; const bf16_t* An;
-                unit_desc(unit + 1, fn, bn, An);
-                issue_A(An, 0, (gs + 1) & 1);
-            }
+            if (s + 1 < nk) issue_A(s + 1, (s + 1) & 1);
             const unsigned char* Hb = halo + cch * HC_HALO_BYTES;
-            const unsigned char* Ab = aring + (gs & 1) * AH_ASTAGE;
+            const unsigned char* Ab = aring + (s & 1) * AH_ASTAGE;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -245,8 +222,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         }
 
         AH_STAMP();
-        // ---- phase 1: modulation sum in registers -> stage[px][16 features] ---------------------------
-        if (!xpf) __syncthreads();              // stage aliases the ring: every wave must be done reading it
+        // ---- phase 1: modulation sum in registers -> stage[px][16 features] (aliases the A ring) ---
+        __syncthreads();
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
             const int px = wq * 64 + tp * 32 + (lane & 31);
@@ -268,11 +245,6 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
             }
         }
         __syncthreads();
-        if (xpf && has_next) {                           // tcs is free again: next unit's slice lands during phase 2
-            int fn, bn; const bf16_t* An;
-            unit_desc(unit + 1, fn, bn, An);
-            issue_tc(fn);
-        }
         AH_STAMP();
         // ---- phase 2: one (pixel, 8 features) item per thread ----------------------------------------
         {
