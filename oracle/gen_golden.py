@@ -98,6 +98,16 @@ def main():
         sampler_out=out_c.numpy(), sampler_noise=np.stack([d.numpy() for d in draws]),
         **{"w::" + k: v for k, v in sd.items() if k.startswith("denoise_fn.")})
 
+    # strided sampler (ddim_sample, 5 of 50 steps) with recorded noise draws
+    net.set_new_noise_schedule(SCHED50, torch.device("cpu"))
+    torch.manual_seed(9)
+    st = torch.get_rng_state()
+    gd = torch.from_numpy(guide[:1])
+    out_d = net.ddim_sample(c1, False, kwargs={"guide": gd})
+    torch.set_rng_state(st)
+    ddraws = np.stack([torch.randn(c1.shape).numpy() for _ in range(6)])
+    np.savez_compressed(os.path.join(OUT, "tiny_ddim.npz"), cond=cond[:1], guide=guide[:1], noise=ddraws, out=out_d.numpy())
+
     # (iii) patch_forward_guide at skip=128/padding=32 on 160x200 (tiny net) -----------------------
     from utils.util import patch_forward_guide
     cond, guide, x_t = synth_inputs(1, 160, 200, seed=5)

@@ -335,6 +335,31 @@ def p_sample_loop(sd: SD, tab: dict, cond: torch.Tensor, guide: torch.Tensor,
     return ret if continous else ret[-1]
 
 
+def ddim_sample(sd: SD, tab: dict, cond: torch.Tensor, guide: torch.Tensor, noises, sampling_timesteps: int = 5,
+                eta: float = 1.0, **fw) -> torch.Tensor:
+    """diffusion.py:247-294 (+ model_predictions :214-245, objective 'pred_noise', clip_x_start=True) with
+    injected noise: noises[0] = x_T, then one tensor per pair with time_next >= 0."""
+    T = len(tab["betas"])
+    times = torch.linspace(-1, T - 1, steps=sampling_timesteps + 1)
+    times = list(reversed(times.int().tolist()))
+    img = noises[0]
+    k = 1
+    for t, t_next in zip(times[:-1], times[1:]):
+        lvl = noise_level_for(tab, t, cond.shape[0])
+        eps = dy3h_forward(sd, torch.cat([cond, img], dim=1), lvl, guide, **fw)
+        x0 = torch.tensor(tab["sqrt_recip_alphas_cumprod"][t]) * img - torch.tensor(tab["sqrt_recipm1_alphas_cumprod"][t]) * eps
+        x0 = x0.clamp(-1.0, 1.0)
+        if t_next < 0:
+            img = x0
+            continue
+        a = torch.tensor(tab["alphas_cumprod"][t]); an = torch.tensor(tab["alphas_cumprod"][t_next])
+        sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+        c = (1 - an - sigma ** 2).sqrt()
+        img = x0 * an.sqrt() + c * eps + sigma * noises[k]
+        k += 1
+    return img
+
+
 def super_resolution(sd: SD, tab: dict, x_in: torch.Tensor, noises, continous: bool = False, **fw):
     """ResiGaussianGuideDY.super_resolution (diffusion.py:473-478)."""
     initx = predictor_forward(sd, x_in)

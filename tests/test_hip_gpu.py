@@ -146,3 +146,52 @@ def test_sr_val_entry_point(tmp_path, monkeypatch):
     assert np.isfinite(psnr) and -1.0 <= ssim <= 1.0      # random-noise targets: SSIM ~ 0
     outs = [f for _, _, fs in os.walk(tmp_path / "experiments") for f in fs if f.endswith("_sr.jpg")]
     assert len(outs) == 2
+
+
+def test_ddim_sample_matches_oracle():
+    """5-step strided sampler (model/diffusion.py:247-294) through the same denoiser boundary."""
+    from oracle import ucdir_oracle as O
+    from ucdir_amd.weights import synth_inputs
+    net, sd = C.build_net(SMALL)
+    sched = dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=0.4)
+    tab = O.schedule_tables(sched)
+    net.set_new_noise_schedule(sched, torch.device("cuda"))
+    cond, guide, _ = map(torch.from_numpy, synth_inputs(1, 64, 64, seed=9))
+    g = torch.Generator().manual_seed(3)
+    noises = [torch.randn(1, 3, 64, 64, generator=g) for _ in range(6)]
+    ref = O.ddim_sample(sd, tab, cond, guide, noises)
+    net.noise_source = lambda shape, device, k: noises[k].to(device)
+    with torch.no_grad():
+        got = net.ddim_sample(cond.cuda(), kwargs={"guide": guide.cuda()})
+    net.noise_source = None
+    m = C.metrics(got, ref)
+    assert m["rel_rms"] < 3e-2, m
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """Reference-style EMA checkpoint (`{prefix}_gen_ema.pth`, training-length schedule buffers included,
+    model/model.py:193-251) loads through DDPM.load_network and reproduces the forward."""
+    from ucdir_amd import model as M
+    from ucdir_amd.weights import synth_inputs, synth_state_dict
+    import bench
+    opt = bench.sid_opt()
+    opt["model"]["unet"].update(channel_mults=[1, 2, 4], res_blocks=1, attn_res=[32])
+    opt["model"]["beta_schedule"] = {"train": dict(schedule="linear", n_timestep=2000, linear_start=1e-6, linear_end=1e-2),
+                                     "val": dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=0.4)}
+    opt["train"] = {"ema_scheduler": {"use": True}}
+    opt["phase"] = "val"
+    net, _ = C.build_net(SMALL, seed=7)
+    net.set_new_noise_schedule(opt["model"]["beta_schedule"]["train"], torch.device("cuda"))
+    prefix = str(tmp_path / "I100_E1")
+    torch.save({k: v.cpu() for k, v in net.state_dict().items()}, prefix + "_gen_ema.pth")
+    opt["path"] = {"resume_state": prefix}
+    ddpm = M.DDPM(opt)
+    ddpm.set_new_noise_schedule(opt["model"]["beta_schedule"]["val"], schedule_phase="val")
+    assert ddpm.netG.betas.shape[0] == 50
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(1, 64, 64, seed=2))
+    lvl = torch.tensor([[0.4]])
+    with torch.no_grad():
+        a = net.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda())
+        b = ddpm.netG.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda())
+        pa, pb = net.predictor(cond.cuda()), ddpm.netG.predictor(cond.cuda())
+    assert torch.equal(a, b) and torch.equal(pa, pb)

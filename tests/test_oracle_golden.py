@@ -79,6 +79,14 @@ def test_tiny_sampler_8_steps(golden_dir):
     np.testing.assert_allclose(out.numpy(), g["sampler_out"], rtol=0, atol=5e-5)
 
 
+def test_tiny_ddim(golden_dir):
+    g = _g(golden_dir, "tiny_ddim.npz")
+    sd = O.to_torch_sd(synth_state_dict(TINY, 0))
+    tab = O.schedule_tables(dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=0.4))
+    out = O.ddim_sample(sd, tab, _t(g["cond"]), _t(g["guide"]), [_t(n) for n in g["noise"]])
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=5e-5)
+
+
 def test_tiny_patch_split(golden_dir):
     g = _g(golden_dir, "tiny_patch.npz")
     sd = O.to_torch_sd(synth_state_dict(TINY, 0))

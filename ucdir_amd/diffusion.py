@@ -145,6 +145,38 @@ class GaussianDiffusion(nn.Module):
         return ret[-1]
 
     @torch.no_grad()
+    def ddim_sample(self, x_in, continous=False, kwargs={}, sampling_timesteps=5, eta=1.0):
+        """model/diffusion.py:247-294: strided sampler over `sampling_timesteps` of the T training steps
+        (eta = 1 -> DDPM-like noise, the reference's hard-coded setting).  Same denoiser boundary, fewer calls."""
+        T = self.num_timesteps
+        times = torch.linspace(-1, T - 1, steps=sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        pairs = list(zip(times[:-1], times[1:]))
+        ac = self._host_tables["alphas_cumprod"]
+        img = self._noise(x_in, 0)
+        imgs = [img]
+        guide = kwargs.get("guide")
+        k = 1
+        for t, t_next in pairs:
+            level, c_recip, c_recipm1, _, _, _ = self.step_coefficients(t)
+            lvl = torch.full((x_in.shape[0], 1), level, dtype=torch.float32, device=x_in.device)
+            eps = self.denoise_fn.forward_split(x_in, img, lvl, guide) if self._small(img) else \
+                self.denoise_fn(torch.cat([x_in, img], dim=1), lvl, guide)
+            x0 = (c_recip * img - c_recipm1 * eps).clamp_(-1.0, 1.0)
+            if t_next < 0:
+                img = x0
+                imgs.append(img)
+                continue
+            a, an = float(ac[t]), float(ac[t_next])
+            sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)) ** 0.5
+            c = (1 - an - sigma ** 2) ** 0.5
+            noise = self._noise(img, k)
+            k += 1
+            img = x0 * (an ** 0.5) + c * eps + sigma * noise
+            imgs.append(img)
+        return img if not continous else torch.stack(imgs, dim=1)
+
+    @torch.no_grad()
     def sample(self, batch_size=1, continous=False):
         raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
 
