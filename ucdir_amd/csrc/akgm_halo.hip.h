@@ -36,10 +36,9 @@ struct AkgmHP {
 __global__ void akgm_tc_kernel(const double* __restrict__ stats, double inv_count, const float* __restrict__ bias,
                                const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc) {
     const int b = blockIdx.y, cls = blockIdx.x;
-    double m = stats[b * 2] * inv_count;
-    double var = stats[b * 2 + 1] * inv_count - m * m;
-    if (var < 0) var = 0;
-    const float mr = (float)m * (float)(1.0 / sqrt(var + 1e-5));
+    float mean, rstd;
+    mean_rstd(stats[b * 2], stats[b * 2 + 1], inv_count, mean, rstd);
+    const float mr = mean * rstd;
     for (int o = threadIdx.x; o < n; o += blockDim.x)
         Tc[((long long)b * 9 + cls) * n + o] = bias[o] + Tb[(long long)cls * n + o] - mr * Tg[(long long)cls * n + o];
 }
@@ -72,6 +71,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     const int y0 = ty * th, x0 = tx * tw;
     const int hcount = (th + 2) * hw;
     const int nslots = th * tw;
+    const float inv_hw = 1.0f / (float)hw, inv_tw = 1.0f / (float)tw;
     const int nunits = (cg == 64) ? 4 : 2;
     const int nchunks = (cg == 64) ? 2 : 1;                 // halo chunks (32 channels each) this workgroup needs
     const int chunk0 = (cg == 64) ? 2 * sec : sec;
@@ -80,10 +80,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 
     float rstd;
     {
-        double m = p.stats[b * 2] * p.inv_count;
-        double var = p.stats[b * 2 + 1] * p.inv_count - m * m;
-        if (var < 0) var = 0;
-        rstd = (float)(1.0 / sqrt(var + 1e-5));
+        float mean_unused;
+        mean_rstd(p.stats[b * 2], p.stats[b * 2 + 1], p.inv_count, mean_unused, rstd);
     }
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
                 const int hp = (i * 8 + wave) * 16 + (lane >> 2);
                 if ((i * 8 + wave) * 16 < hcount) {
                     if (hp < hcount) {
-                        const int hr = hp / hw, hc = hp - hr * hw;
+                        const int hr = fdiv_small(hp, inv_hw), hc = hp - hr * hw;
                         int gy = y0 + hr, gx = x0 + hc;
                         gy = gy > p.H + 1 ? p.H + 1 : gy;
                         gx = gx > p.W + 1 ? p.W + 1 : gx;
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         int slot = wq * 64 + tp * 32 + (lane & 31);
         const bool inb = slot < nslots;
         slot = inb ? slot : nslots - 1;
-        const int r = slot / tw, c = slot - r * tw;
+        const int r = fdiv_small(slot, inv_tw), c = slot - r * tw;
         hp0[tp] = r * hw + c;
         int y = y0 + r, x = x0 + c;
         valid[tp] = inb && y < p.H && x < p.W;
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         {
             const int px = tid >> 1, f8 = (tid & 1) * 8;
             if (px < nslots) {
-                const int r = px / tw, c = px - r * tw;
+                const int r = fdiv_small(px, inv_tw), c = px - r * tw;
                 const int y = y0 + r, x = x0 + c;
                 if (y < p.H && x < p.W) {
                     const long long off = ((long long)(y + 1) * p.Wp + (x + 1)) * p.C + fbase + f8;

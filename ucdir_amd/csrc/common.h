@@ -32,6 +32,21 @@ __device__ __forceinline__ uint4 pack8_bf16(const float* v) {
 }
 
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// x / d for small non-negative ints (x < 2^15, d <= 1024) with inv = 1.0f / d: the +0.5 keeps the product at least
+// 0.5/d away from an integer, far more than the fp32 rounding error, so the truncation is exact (3 VALU, no division)
+__device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+// GroupNorm(1 group) mean / rstd of one sample from its fp64 (sum, sum of squares): the cancellation-prone
+// part stays in fp64 (3 operations), the reciprocal square root is v_rsq_f32 + one Newton step (<= 1 ulp)
+__device__ __forceinline__ void mean_rstd(double S, double Q, double inv_count, float& mean, float& rstd) {
+    const double m = S * inv_count;
+    float v = (float)(Q * inv_count - m * m);
+    v = (v > 0.f ? v : 0.f) + 1e-5f;
+    float r = __builtin_amdgcn_rsqf(v);
+    r = r * (1.5f - 0.5f * v * r * r);
+    mean = (float)m; rstd = r;
+}
+
 // swish with v_rcp_f32 instead of an IEEE divide (1 ulp; the result is rounded to bf16 anyway)
 // act codes of the epilogues: 0 none, 1 swish, 2 LeakyReLU(0.2) as max(0.2x, x) (model/ucdir.py:414-416)
 __device__ inline float act_apply(float v, int act);

@@ -95,16 +95,14 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     const int y0 = ty * th, x0 = tx * tw;
     const int hcount = (th + 2) * hw;
     const int nslots = th * tw;
+    const float inv_hw = 1.0f / (float)hw, inv_tw = 1.0f / (float)tw;
 
     {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
             double S = p.stats0[b * 2], Q = p.stats0[b * 2 + 1];
             if (p.stats1) { S += p.stats1[b * 2]; Q += p.stats1[b * 2 + 1]; }
-            double m = S * p.inv_count;
-            double var = Q * p.inv_count - m * m;
-            if (var < 0) var = 0;
-            mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
+            mean_rstd(S, Q, p.inv_count, mean, rstd);
         }
         if (tid == 0) { scal[0] = mean; scal[1] = rstd; }
         // Tc[cls][f] = bias + Tb[cls] - mean*rstd*Tg[cls] for this workgroup's TM features (read in phase 2)
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int hp = (i * 8 + wave) * 16 + (lane >> 2);
-        int hr = hp / hw, hc = hp - hr * hw;
+        int hr = fdiv_small(hp, inv_hw), hc = hp - hr * hw;
         int gy = y0 + hr, gx = x0 + hc;
         gy = gy > p.H + 1 ? p.H + 1 : gy;
         gx = gx > p.W + 1 ? p.W + 1 : gx;
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     for (int tp = 0; tp < NTP; ++tp) {
         int slot = wq * TPW + tp * 32 + (lane & 31);
         slot = slot < nslots ? slot : nslots - 1;
-        const int r = slot / tw, c = slot - r * tw;
+        const int r = fdiv_small(slot, inv_tw), c = slot - r * tw;
         hp0[tp] = r * hw + c;
     }
 
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             const int f8 = (it - px * nf8) * 8;
             const int slot = pass * PXH + px;
             if (slot >= nslots) continue;
-            const int r = slot / tw, cc = slot - r * tw;
+            const int r = fdiv_small(slot, inv_tw), cc = slot - r * tw;
             const int y = y0 + r, x = x0 + cc;                 // 0-based valid coordinates
             if (y >= p.H || x >= p.W) continue;
             const int f = fbase + f8;
@@ -310,9 +308,12 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 const float4 t1 = *reinterpret_cast<const float4*>(&tcs[cls * TM + f8 + 4]);
                 v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
             }
-            if (p.act) {
+            if (p.act == 1) {                      // one uniform branch per item, not one per element
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], p.act);
+                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
             }
             if (p.res) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);

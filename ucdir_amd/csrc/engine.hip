@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "cgemm.hip.h"
 #include "conv_halo.hip.h"
 #include "akgm_halo.hip.h"
+#include "akgm_pre.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -69,6 +71,7 @@ struct ConvW {
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
+    bf16_t* Apre = nullptr;        // cg 8 / 16: LDS image for akgm_pre.hip.h
     int C = 0, cg = 0, Kpad = 0;
 };
 
@@ -94,6 +97,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
+    if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
     return W;
 }
 
@@ -101,7 +105,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 // ---- optional per-launch HIP-event timing (bench.py roofline) -------------------------------------
-struct ProfEntry { int key; double flops; double bytes; hipEvent_t e0, e1; };
+struct ProfEntry { int key; double flops; double bytes; hipEvent_t e0, e1; int dH = 0, dW = 0, dCin = 0, dCout = 0; };
 struct Profiler {
     bool on = false;
     std::vector<ProfEntry> entries;
@@ -149,6 +153,7 @@ static void launch_cgemm(const GemmP& p, int TM, int epi, hipStream_t st) {
     int mode = p.cols_mode; if (mode == COLS_S1 && p.in_compact) mode = MODE_S1C;
     e.key = (TM == 128 ? 100 : 0) + (epi == EPI_AKGM ? 10 : 0) + (epi == EPI_AKGM ? 0 : mode);
     gemm_work(p, epi, e.flops, e.bytes);
+    e.dH = p.H; e.dW = p.W; e.dCin = p.cg * p.ntaps; e.dCout = p.nfeat;
     e.e0 = g_prof.get(); e.e1 = g_prof.get();
     HIPC(hipEventRecord(e.e0, st));
     launch_cgemm_impl(p, TM, epi, st);
@@ -241,6 +246,7 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
     const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1);
     if (g_prof.on) {
         ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
+        e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
         hipLaunchKernelGGL((conv3x3_halo_kernel<TM>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
@@ -335,15 +341,19 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     static bool attr_done = false;
     if (!attr_done) {
         HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
+        HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<8>::LDS));
+        HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<16>::LDS));
         attr_done = true;
     }
+    static const bool use_pre = !getenv("UCDIR_NO_PRE");
+    const bool pre = use_pre && w.Apre != nullptr;
     static float* tcbuf = nullptr; static size_t tccap = 0;
     const size_t need = (size_t)y.B * 9 * 8 * w.C * sizeof(float);
     if (need > tccap) { if (tcbuf) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tcbuf); } HIPC(hipMalloc((void**)&tcbuf, need)); tccap = need; }
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
     hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf);
     AkgmHP p;
-    p.A = w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
+    p.A = pre ? w.Apre : w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
     p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
     choose_tile(y.H, y.W, p.th, p.tw);
     p.tiles_x = (y.W + p.tw - 1) / p.tw; p.tiles_y = (y.H + p.th - 1) / p.th; p.nbatch = y.B;
@@ -357,12 +367,17 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.partials = y.partials;
     const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.dbg = nullptr;
+    auto launch = [&]() {
+        if (pre && w.cg == 8) hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
+        else if (pre) hipLaunchKernelGGL(akgm_pre_kernel<16>, dim3(nblk), dim3(HC_THREADS), AkPre<16>::LDS, st, p);
+        else hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+    };
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
     if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
     HIPC(hipMemset(dbgbuf, 0, 256 * 8));
     p.dbg = dbgbuf;
-    hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+    launch();
     {
         unsigned long long h[256];
         HIPC(hipStreamSynchronize(st));
@@ -374,15 +389,16 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = 111; e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        ProfEntry e; e.key = pre ? 112 : 111; e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
+        e.dH = y.H; e.dW = y.W; e.dCin = w.C; e.dCout = w.C;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
-        hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        launch();
         HIPC(hipEventRecord(e.e1, st));
         g_prof.entries.push_back(e);
     } else {
-        hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        launch();
     }
     HIPC(hipGetLastError());
     y.npart = p.npart; finalize_stats(y, st);
@@ -948,8 +964,12 @@ int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double
     API_BEGIN
     HIPC(hipStreamSynchronize((hipStream_t)stream));
     std::map<int, int> idx; int n = 0;
+    static const bool detail = getenv("UCDIR_PROF_DETAIL") != nullptr;
+    struct Det { int n = 0; double ms = 0, flops = 0; };
+    std::map<std::array<int, 5>, Det> det;
     for (auto& e : g_prof.entries) {
         float t = 0.f; HIPC(hipEventElapsedTime(&t, e.e0, e.e1));
+        if (detail) { Det& d = det[{e.key, e.dH, e.dW, e.dCin, e.dCout}]; d.n++; d.ms += t; d.flops += e.flops; }
         auto it = idx.find(e.key);
         int r;
         if (it == idx.end()) { if (n >= cap) continue; r = n++; idx[e.key] = r; keys[r] = e.key; launches[r] = 0; ms[r] = 0; flops[r] = 0; bytes[r] = 0; }
@@ -957,6 +977,9 @@ int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double
         launches[r] += 1; ms[r] += t; flops[r] += e.flops; bytes[r] += e.bytes;
     }
     *nrows = n;
+    for (auto& kv : det)
+        fprintf(stderr, "PROF key=%d H=%d W=%d cin=%d cout=%d launches=%d ms=%.4f TF=%.1f\n", kv.first[0], kv.first[1], kv.first[2],
+                kv.first[3], kv.first[4], kv.second.n, kv.second.ms, kv.second.flops / (kv.second.ms * 1e9 + 1e-30));
     g_prof.entries.clear(); g_prof.used = 0;
     API_END
 }

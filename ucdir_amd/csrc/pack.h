@@ -123,6 +123,36 @@ static inline PackedAkgm pack_akgm(const float* wsp, const float* bsp, const flo
     return P;
 }
 
+// LDS image of the spdyconv weights for akgm_pre.hip.h (cg = 8 / 16): [unit][k16 step][k half][128 rows][8],
+// a unit being 128 MFMA rows = 16 output features x 8 kernel sets (cg 8: two adjacent groups; cg 16: one group).
+// Row R of a unit: 32-row tile t32 = R/32, rho = R%32 -> lane half hr = (rho>>2)&1, q = (rho>>4)&1, set s; feature
+// 4*t32 + 2*hr + q, so a lane's two features are adjacent.  k: cg 8 -> (tap 2j + half, channel e), tap 9 = 0;
+// cg 16 -> (tap j, channel 8*half + e).  Values are W*gamma rounded exactly as in pack_akgm (same fold tables).
+static inline std::vector<bf16_t> pack_akgm_pre(const float* wsp, const float* gamma, int C) {
+    const int cg = C / 8;
+    const int nk16 = (cg == 8) ? 5 : 9;
+    const int nunits = C / 16;
+    std::vector<bf16_t> img((size_t)nunits * nk16 * 2 * 128 * 8, 0);
+    for (int U = 0; U < nunits; ++U)
+        for (int R = 0; R < 128; ++R) {
+            const int t32 = R >> 5, rho = R & 31;
+            const int hr = (rho >> 2) & 1, q = (rho >> 4) & 1, s = (rho & 3) + 4 * ((rho >> 3) & 1);
+            const int c = U * 16 + 4 * t32 + 2 * hr + q;          // output feature
+            const int g = c / cg;                                  // its group
+            const int o = 8 * c + s;
+            for (int j = 0; j < nk16; ++j)
+                for (int hk = 0; hk < 2; ++hk)
+                    for (int e = 0; e < 8; ++e) {
+                        const int tap = (cg == 8) ? 2 * j + hk : j;
+                        const int ci = (cg == 8) ? e : 8 * hk + e;
+                        if (tap > 8) continue;
+                        img[(((size_t)U * nk16 + j) * 2 + hk) * 1024 + (size_t)R * 8 + e] =
+                            f2bf(wsp[((size_t)o * cg + ci) * 9 + tap] * gamma[g * cg + ci]);
+                    }
+        }
+    return img;
+}
+
 // Upsample(nearest x2) + conv3x3 as four parity classes of 2x2 convolutions on the low-res grid:
 //   out[2y+py][2x+px] = sum_{dy,dx in {0,1}} Wp[py][px][dy][dx] . in[y+py+dy-1][x+px+dx-1]
 // with Wp = sums of the original taps that land on the same source pixel:
