@@ -18,12 +18,13 @@ struct AkgmHP {
     const bf16_t* A; int Kpad;                 // [8 groups][C rows][Kpad], K order see pack_akgm_halo
     const bf16_t* h; long long h_bstride;      // swish(conv1), zero-bordered NHWC, C channels
     int C, cg, H, W, Wp, th, tw, tiles_x, tiles_y, nbatch;
-    const double* stats; double inv_count;
+    const stat_t* stats; double inv_count;
     const float* Tc;                           // [B][9][8C]: bias + Tb - mean*rstd*Tg (akgm_tc_kernel), original row order
     const float* G; long long g_bstride; const float* attw;
     const bf16_t* res; long long res_bstride;
     bf16_t* out; long long out_bstride;
     float* partials; int npart;
+    stat_t* stats_out;                         // != nullptr: add the partial sums here (stat_add) instead of `partials`
     unsigned long long* dbg;
 };
 
@@ -33,11 +34,11 @@ struct AkgmHP {
 #define AH_LDS (2 * HC_HALO_BYTES + 2 * AH_ASTAGE + 128 + 9 * AH_TM * 4)
 
 // Tc[b][cls][o] = bias[o] + Tb[cls][o] - mean_b * rstd_b * Tg[cls][o]   (once per launch; grid (9, B))
-__global__ void akgm_tc_kernel(const double* __restrict__ stats, double inv_count, const float* __restrict__ bias,
+__global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_count, const float* __restrict__ bias,
                                const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc) {
     const int b = blockIdx.y, cls = blockIdx.x;
     float mean, rstd;
-    mean_rstd(stats[b * 2], stats[b * 2 + 1], inv_count, mean, rstd);
+    mean_rstd(stat_val(stats[b * 2]), stat_val(stats[b * 2 + 1]), inv_count, mean, rstd);
     const float mr = mean * rstd;
     for (int o = threadIdx.x; o < n; o += blockDim.x)
         Tc[((long long)b * 9 + cls) * n + o] = bias[o] + Tb[(long long)cls * n + o] - mr * Tg[(long long)cls * n + o];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     float rstd;
     {
         float mean_unused;
-        mean_rstd(p.stats[b * 2], p.stats[b * 2 + 1], p.inv_count, mean_unused, rstd);
+        mean_rstd(stat_val(p.stats[b * 2]), stat_val(p.stats[b * 2 + 1]), p.inv_count, mean_unused, rstd);
     }
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
-    if (p.partials) {
+    if (p.partials || p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
         __syncthreads();
@@ -281,8 +282,11 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         if (tid == 0) {
             float t1 = 0.f, t2 = 0.f;
             for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2 += scal[3 + w * 2]; }
-            float* pp = p.partials + ((long long)b * p.npart + (long long)(ty * p.tiles_x + tx) * nsec + sec) * 2;
-            pp[0] = t1; pp[1] = t2;
+            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2);
+            else {
+                float* pp = p.partials + ((long long)b * p.npart + (long long)(ty * p.tiles_x + tx) * nsec + sec) * 2;
+                pp[0] = t1; pp[1] = t2;
+            }
         }
     }
 }

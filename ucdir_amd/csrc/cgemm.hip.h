@@ -93,8 +93,9 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     if (tid == 0) {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
-            double S = p.stats0[b * 2], Q = p.stats0[b * 2 + 1];
-            if (p.stats1) { S += p.stats1[b * 2]; Q += p.stats1[b * 2 + 1]; }
+            stat_t Si = p.stats0[b * 2], Qi = p.stats0[b * 2 + 1];
+            if (p.stats1) { Si += p.stats1[b * 2]; Qi += p.stats1[b * 2 + 1]; }
+            const double S = stat_val(Si), Q = stat_val(Qi);
             double m = S * p.inv_count;
             double var = Q * p.inv_count - m * m;
             if (var < 0) var = 0;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
         }
     }
-    if (p.partials) {
+    if (p.partials || p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             s1 += __shfl_xor(s1, off);
@@ -398,10 +399,13 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         if (lane == 0) { scal[2 + wave * 2] = s1; scal[3 + wave * 2] = s2; }
         __syncthreads();
         if (tid == 0) {
-            float t1 = scal[2] + scal[4] + scal[6] + scal[8];
-            float t2 = scal[3] + scal[5] + scal[7] + scal[9];
-            float* pp = p.partials + ((long long)b * p.npart + (long long)tcol * p.rowtiles + rowtile) * 2;
-            pp[0] = t1; pp[1] = t2;
+            const float t1 = scal[2] + scal[4] + scal[6] + scal[8];
+            const float t2 = scal[3] + scal[5] + scal[7] + scal[9];
+            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2);
+            else {
+                float* pp = p.partials + ((long long)b * p.npart + (long long)tcol * p.rowtiles + rowtile) * 2;
+                pp[0] = t1; pp[1] = t2;
+            }
         }
     }
 }

@@ -54,13 +54,28 @@ __device__ inline float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.
 
 __device__ inline float act_apply(float v, int act) { return act == 1 ? silu_fast(v) : (act == 2 ? fmaxf(0.2f * v, v) : v); }
 
+// GroupNorm statistics of an activation: per-sample (sum, sum of squares) kept as 2^-20 FIXED POINT in 64-bit
+// integers.  Every producer workgroup adds its fp32 partial with one fire-and-forget integer atomic per value:
+// integer addition is associative, so the result is bit-identical whatever order the workgroups retire in (an
+// fp64 atomic would not be), nobody waits on anything, and the per-activation reduction launch
+// (stats_finalize_kernel, 69 per forward) disappears.  Resolution 1e-6 absolute against sums of 1e3..1e7;
+// range +-8.8e12.  The accumulators of all activations sit in one slab that forward() zeroes with one memset.
+typedef long long stat_t;
+#define UCDIR_STAT_SCALE 1048576.0
+__device__ __forceinline__ double stat_val(stat_t v) { return (double)v * (1.0 / UCDIR_STAT_SCALE); }
+__device__ __forceinline__ stat_t stat_fx(double v) { return __double2ll_rn(v * UCDIR_STAT_SCALE); }
+__device__ __forceinline__ void stat_add(stat_t* dst, float t1, float t2) {      // call from ONE thread of the workgroup
+    (void)__hip_atomic_fetch_add(dst, stat_fx((double)t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(dst + 1, stat_fx((double)t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Activation tensor in HBM: zero-bordered NHWC bf16, [B][H+2][W+2][C].  The one-pixel zero
 // border makes every 3x3 tap of an interior pixel an in-bounds read of the right value, so the
 // implicit GEMM needs no per-tap predication.  Borders are zeroed once and never written.
 struct Act {
     bf16_t* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
-    double* stats = nullptr;       // [B][2] (sum, sum of squares) over the valid region
+    stat_t* stats = nullptr;       // [B][2] (sum, sum of squares) over the valid region, fixed point (stat_val)
     float* partials = nullptr;     // [B][npart][2] per-workgroup partial sums
     int npart = 0;                 // partial sums written by the last producer
     int npart_cap = 0;             // capacity of `partials`
@@ -94,7 +109,7 @@ struct GemmP {
     int up_phase;                   // conv3x3_halo: nearest-x2 + 3x3 as four 2x2 parity convolutions
     // epilogue
     float alpha; int fold; int act;
-    const double* stats0; const double* stats1; double inv_count;   // GN of the input (fold)
+    const stat_t* stats0; const stat_t* stats1; double inv_count;   // GN of the input (fold)
     const float* bias; const float* Tb; const float* Tg; int tab_ld;  // tables [ncls][tab_ld]
     const bf16_t* res; long long res_bstride; int res_ld; int res_coff;
     void* out; long long out_bstride; int out_ld; int out_coff; int out_f32; int out_compact;
@@ -102,6 +117,7 @@ struct GemmP {
     int shuffle_c;                      // > 0: ConvTranspose2d(2,2): feature f = q*shuffle_c + o goes to pixel (2y+q/2, 2x+q%2), channel o
     int nfeat;               // valid output features (rows) in total
     float* partials; int npart;
+    stat_t* stats_out;                      // != nullptr: add this launch's partial sums here (stat_add) instead of `partials`
     // AKGM
     const float* G; long long g_bstride;   // guide branch, compact [B][H*W][8]
     const float* attw;                      // [B][8]

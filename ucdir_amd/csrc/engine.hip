@@ -60,7 +60,17 @@ struct DevPool {
         if (!v.empty()) HIPC(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
         return p;
     }
-    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); bytes = 0; }
+    // statistics accumulators of every activation in this pool: one slab, zeroed with one memset per forward
+    static constexpr size_t STAT_CAP = 1 << 15;
+    stat_t* stat_slab = nullptr; size_t stat_used = 0;
+    stat_t* alloc_stats(int B) {
+        if (!stat_slab) stat_slab = (stat_t*)alloc(STAT_CAP * sizeof(stat_t), true);
+        if (stat_used + 2 * (size_t)B > STAT_CAP) throw std::runtime_error("DevPool: statistics slab exhausted");
+        stat_t* p = stat_slab + stat_used; stat_used += 2 * (size_t)B;
+        return p;
+    }
+    void zero_stats(hipStream_t st) { if (stat_used) HIPC(hipMemsetAsync(stat_slab, 0, stat_used * sizeof(stat_t), st)); }
+    void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); bytes = 0; stat_slab = nullptr; stat_used = 0; }
     ~DevPool() { release(); }
 };
 
@@ -195,6 +205,8 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 static void zero_gemm(GemmP& p) { std::memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.groups_per_wg = 1; }
 
+// only for producers that still write per-workgroup partials (the stem); the GEMM kernels add their partial sums
+// straight into y.stats (stat_add, common.h), which forward() zeroes beforehand
 static void finalize_stats(Act& y, hipStream_t st) {
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(y.B), dim3(256), 0, st, y.partials, y.npart, y.stats);
     HIPC(hipGetLastError());
@@ -219,7 +231,7 @@ static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats =
     if (with_stats) {
         a.npart = a.npart_cap = npart_for(H, W, C);
         a.partials = (float*)pool.alloc((size_t)B * a.npart * 2 * sizeof(float), true);
-        a.stats = (double*)pool.alloc((size_t)B * 2 * sizeof(double), true);
+        a.stats = pool.alloc_stats(B);
     }
     return a;
 }
@@ -306,7 +318,7 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (want_stats) {
         p.npart = p.tiles * p.rowtiles;
         require(p.npart <= y.npart_cap, "run_conv: partial buffer too small");
-        p.partials = y.partials;
+        p.stats_out = y.stats;
     }
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
@@ -333,7 +345,6 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         fprintf(stderr, "\n");
     }
 #endif
-    if (want_stats) { y.npart = p.npart; finalize_stats(y, st); }
 }
 
 // halo-tile AKGM kernel (akgm_halo.hip.h): 8 / 16 / 32 / 64 channels per group
@@ -364,7 +375,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
     p.npart = p.tiles_x * p.tiles_y * nsec;
     require(p.npart <= y.npart_cap, "run_akgm_halo: partial buffer too small");
-    p.partials = y.partials;
+    p.partials = nullptr; p.stats_out = y.stats;
     const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.dbg = nullptr;
     auto launch = [&]() {
@@ -401,7 +412,6 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
         launch();
     }
     HIPC(hipGetLastError());
-    y.npart = p.npart; finalize_stats(y, st);
 }
 
 // AKGM tail of a block: y = swish(sum_s spdyconv(GN2(h1))[c,s] * G[s] * attw[s]) + res
@@ -432,9 +442,8 @@ static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float*
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.npart = p.tiles * p.rowtiles;
     require(p.npart <= y.npart_cap, "run_akgm: partial buffer too small");
-    p.partials = y.partials;
+    p.stats_out = y.stats;
     launch_cgemm(p, TM, EPI_AKGM, st);
-    y.npart = p.npart; finalize_stats(y, st);
 }
 
 struct AttnBufs {
@@ -522,9 +531,8 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
         p.npart = p.tiles * p.rowtiles;
         require(p.npart <= y.npart_cap, "attention: partial buffer too small");
-        p.partials = y.partials;
+        p.stats_out = y.stats;
         launch_cgemm(p, 128, EPI_STD, st);
-        y.npart = p.npart; finalize_stats(y, st);
     }
     HIPC(hipGetLastError());
 }
@@ -780,6 +788,7 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
 }
 
 static void forward(ucdir_ctx* c, const float* cond, const float* xt, const float* level, float* eps, hipStream_t st) {
+    c->apool.zero_stats(st);          // every activation's (sum, sum of squares) accumulator, see stat_add()
     require(c->finalized, "weights not finalized");
     require(c->guide_ready, "ucdir_prepare_guide must be called before ucdir_unet_forward");
     const int B = c->B, inner = c->cfg.inner_channel;
@@ -1015,8 +1024,10 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
     run_conv(w, a0, x1 ? &a1 : nullptr, out, mode, silu, residual ? &res : nullptr, true, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, cout, Ho, Wo);
     HIPC(hipGetLastError());
-    if (stats_out_host) HIPC(hipMemcpyAsync(stats_out_host, out.stats, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, st));
+    std::vector<stat_t> sfx;
+    if (stats_out_host) { sfx.resize((size_t)2 * B); HIPC(hipMemcpyAsync(sfx.data(), out.stats, sizeof(stat_t) * 2 * B, hipMemcpyDeviceToHost, st)); }
     HIPC(hipStreamSynchronize(st));
+    for (size_t i = 0; i < sfx.size(); ++i) stats_out_host[i] = (double)sfx[i] / UCDIR_STAT_SCALE;     // fixed point -> sums
     API_END
 }
 

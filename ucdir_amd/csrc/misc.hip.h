@@ -6,7 +6,7 @@
 // GroupNorm statistics: reduce per-workgroup partial sums (written by producer epilogues, fp32)
 // into per-sample (sum, sumsq) in double.  Deterministic (fixed order), one block per sample.
 // ------------------------------------------------------------------------------------------------
-__global__ void stats_finalize_kernel(const float* __restrict__ partials, int npart, double* __restrict__ stats) {
+__global__ void stats_finalize_kernel(const float* __restrict__ partials, int npart, stat_t* __restrict__ stats) {
     const int b = blockIdx.x;
     const float* pp = partials + (long long)b * npart * 2;
     double s1 = 0, s2 = 0;
@@ -18,11 +18,11 @@ __global__ void stats_finalize_kernel(const float* __restrict__ partials, int np
         if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stats[b * 2] = sh[0][0]; stats[b * 2 + 1] = sh[1][0]; }
+    if (threadIdx.x == 0) { stats[b * 2] = stat_fx(sh[0][0]); stats[b * 2 + 1] = stat_fx(sh[1][0]); }
 }
 
 // direct statistics of an activation tensor (tests / inputs produced outside the GEMM core)
-__global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int C, double* __restrict__ stats) {
+__global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int C, stat_t* __restrict__ stats) {
     const int b = blockIdx.x;
     const int Wp = W + 2;
     const long long bs = (long long)(H + 2) * Wp * C;
@@ -44,7 +44,7 @@ __global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int
         if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stats[b * 2] = sh[0][0]; stats[b * 2 + 1] = sh[1][0]; }
+    if (threadIdx.x == 0) { stats[b * 2] = stat_fx(sh[0][0]); stats[b * 2 + 1] = stat_fx(sh[1][0]); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -156,13 +156,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ con
 // HBM-bound: 16 B per lane in, 16 B out.  grid (blocks, 1, B)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int H, int W, int C,
-                                                      const double* __restrict__ stats, double inv_count,
+                                                      const stat_t* __restrict__ stats, double inv_count,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int b = blockIdx.z;
     float mean, rstd;
     {
-        double m = stats[b * 2] * inv_count;
-        double var = stats[b * 2 + 1] * inv_count - m * m;
+        double m = stat_val(stats[b * 2]) * inv_count;
+        double var = stat_val(stats[b * 2 + 1]) * inv_count - m * m;
         if (var < 0) var = 0;
         mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
