@@ -356,8 +356,10 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
         HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<16>::LDS));
         attr_done = true;
     }
-    static const bool use_pre = !getenv("UCDIR_NO_PRE");
-    const bool pre = use_pre && w.Apre != nullptr;
+    // resident-weights kernel: on by default for 8 channels per group (288^2 level, -5 % vs the ring kernel in same-box
+    // A/B); for 16 per group it measured +7 % slower (exposed reload of unit 1), so it stays opt-in (UCDIR_PRE16)
+    static const bool use_pre = !getenv("UCDIR_NO_PRE"), use_pre16 = getenv("UCDIR_PRE16") != nullptr;
+    const bool pre = use_pre && w.Apre != nullptr && (w.cg == 8 || use_pre16);
     static float* tcbuf = nullptr; static size_t tccap = 0;
     const size_t need = (size_t)y.B * 9 * 8 * w.C * sizeof(float);
     if (need > tccap) { if (tcbuf) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tcbuf); } HIPC(hipMalloc((void**)&tcbuf, need)); tccap = need; }
