@@ -619,6 +619,7 @@ struct ucdir_ctx {
     float *mlp_w1 = nullptr, *mlp_b1 = nullptr, *mlp_w2 = nullptr, *mlp_b2 = nullptr, *tw = nullptr;
     float *fin_gamma = nullptr, *fin_beta = nullptr;
     ConvW fin_conv;
+    bf16_t* fin_w = nullptr; float* fin_b = nullptr;   // weight fragments + bias of the fused final kernel (cout <= 4, C % 32 == 0)
     Act fin_act;                        // swish(GN(x)) feeding the final conv
     // shape-dependent state
     DevPool apool;
@@ -729,6 +730,10 @@ static void finalize_weights(ucdir_ctx* c) {
     c->fin_beta = c->wpool.upload(W_(c, "final_conv.0.bias", fc));
     c->fin_conv = upload_conv(c->wpool, W_(c, "final_conv.3.weight", (size_t)cfg.out_channel * fc * 9).data(),
                               W_(c, "final_conv.3.bias", cfg.out_channel).data(), nullptr, nullptr, cfg.out_channel, fc, 3);
+    if (cfg.out_channel <= 4 && fc % 32 == 0) {
+        c->fin_w = c->wpool.upload(pack_final_frags(W_(c, "final_conv.3.weight", (size_t)cfg.out_channel * fc * 9).data(), cfg.out_channel, fc));
+        c->fin_b = c->wpool.upload(W_(c, "final_conv.3.bias", cfg.out_channel));
+    }
     c->host.clear();
     c->finalized = true;
 }
@@ -832,14 +837,30 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         cur = &r.out;
         if (d.push_skip) skips.push_back(cur);
     }
-    // final_conv: swish(GN(x)) (HBM-bound pass) then conv3x3 C -> out_channel on the MFMA core, fp32 NCHW crop
+    // final_conv: GroupNorm + swish + conv3x3 C -> out_channel in one HBM-bound kernel (fp32 NCHW crop); wider heads
+    // (out_channel > 4) take the activation pass + the MFMA conv
     {
-        const int C = cur->C;
-        hipLaunchKernelGGL(gn_silu_kernel, dim3(2048, 1, B), dim3(256), 0, st, cur->p, c->fin_act.p, c->Hc, c->Wc, C,
-                           cur->stats, 1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta);
-        HIPC(hipGetLastError());
-        Act dummy; dummy.B = B; dummy.H = c->Hc; dummy.W = c->Wc; dummy.C = c->fin_conv.cout;
-        run_conv(c->fin_conv, c->fin_act, nullptr, dummy, COLS_S1, 0, nullptr, false, st, eps, c->H, c->W);
+        const int C = cur->C, co = c->cfg.out_channel;
+        static const bool fused = !getenv("UCDIR_NO_FUSED_FINAL");
+        if (fused && c->fin_w) {
+            const dim3 grid((c->Wc + 15) / 16, (c->Hc + 15) / 16, B);
+            const size_t lds = (size_t)324 * (2 * C + 16) + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C;
+            require(lds <= 160 * 1024, "final conv: channel count too large for the fused kernel");
+            static bool attr_done = false;
+            if (!attr_done) {
+                HIPC(hipFuncSetAttribute((const void*)final_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(final_conv_kernel, grid, dim3(256), lds, st, cur->p, c->Hc, c->Wc, C, cur->stats,
+                               1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b, co, eps, c->H, c->W);
+            HIPC(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(gn_silu_kernel, dim3(2048, 1, B), dim3(256), 0, st, cur->p, c->fin_act.p, c->Hc, c->Wc, C,
+                               cur->stats, 1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta);
+            HIPC(hipGetLastError());
+            Act dummy; dummy.B = B; dummy.H = c->Hc; dummy.W = c->Wc; dummy.C = c->fin_conv.cout;
+            run_conv(c->fin_conv, c->fin_act, nullptr, dummy, COLS_S1, 0, nullptr, false, st, eps, c->H, c->W);
+        }
     }
 }
 

@@ -153,6 +153,22 @@ static inline std::vector<bf16_t> pack_akgm_pre(const float* wsp, const float* g
     return img;
 }
 
+// A fragments of final_conv_kernel (misc.hip.h): [step = tap * (C/32) + c32][lane][8] bf16 for v_mfma_f32_16x16x32_bf16,
+// lane = (k group g = lane >> 4, row = lane & 15): W[row][c32*32 + g*8 + e][tap], rows >= cout zero.  w: [cout][C][3][3]
+static inline std::vector<bf16_t> pack_final_frags(const float* w, int cout, int C) {
+    const int nc = C / 32;
+    std::vector<bf16_t> f((size_t)9 * nc * 64 * 8, 0);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c32 = 0; c32 < nc; ++c32)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 15, g = lane >> 4;
+                if (row >= cout) continue;
+                for (int e = 0; e < 8; ++e)
+                    f[(((size_t)tap * nc + c32) * 64 + lane) * 8 + e] = f2bf(w[((size_t)row * C + c32 * 32 + g * 8 + e) * 9 + tap]);
+            }
+    return f;
+}
+
 // Upsample(nearest x2) + conv3x3 as four parity classes of 2x2 convolutions on the low-res grid:
 //   out[2y+py][2x+px] = sum_{dy,dx in {0,1}} Wp[py][px][dy][dx] . in[y+py+dy-1][x+px+dx-1]
 // with Wp = sums of the original taps that land on the same source pixel:
