@@ -57,7 +57,7 @@ __device__ __forceinline__ void hc_wait_vm(int n) {
     }
 }
 
-template <int TM>
+template <int TM, bool DUAL = false>
 __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WM = TM / 64;               // waves along rows
@@ -132,7 +132,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     }
     const int nchunks = p.cg / HC_BK;
     const int nh_min = ((hcount + 15) / 16) / 8;    // halo staging instructions every wave issues (some issue one more)
-    const int ntap = p.up_phase ? 4 : 9;
+    // DUAL (64-row tiles only): a second accumulator set carries the block's res_conv as a 10th tap
+    static_assert(!DUAL || TM == 64, "fused res_conv needs the 64-row tile");
+    constexpr bool res_fused = DUAL;
+    const int ntap = p.up_phase ? 4 : (res_fused ? 10 : 9);   // tap 9 = the block's 1x1 res_conv on the centre pixel
     const int nsteps_c = (ntap + TPS - 1) / TPS;   // steps per chunk
     const int nk = nchunks * nsteps_c;
     auto issue_halo = [&](int c, int buf) {
@@ -188,12 +191,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     }
 
     f32x16_t acc[2][NTP];
+    f32x16_t acc2[DUAL ? 2 : 1][NTP];           // res_conv(x) of the same rows / pixels (DUAL only)
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tp = 0; tp < NTP; ++tp)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[tm][tp][e] = 0.f; if (DUAL) acc2[DUAL ? tm : 0][tp][e] = 0.f; }
 
 #ifdef UCDIR_TIMING
     const bool dbg_on = p.dbg && (lid == gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
@@ -224,8 +228,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             const int t = TPS * u + tt;
             if (t < ntap) {
                 const unsigned char* Ab = aring + (s & 1) * ASTAGE + tt * (TM * HC_BK * 2);
+                const bool is_res = DUAL && t == 9;                 // wave-uniform
                 int sh;
                 if (p.up_phase) sh = (py + (t >> 1)) * hw + (pxp + (t & 1));
+                else if (is_res) sh = hw + 1;
                 else { const int ky = tap_ky(t); sh = ky * hw + (t - 3 * ky); }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -239,11 +245,19 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                         const int hp = hp0[tp] + sh;
                         bfr[tp] = *reinterpret_cast<const bf16x8_t*>(Hb + hp * 64 + ((kch ^ ((hp >> 2) & 3)) << 4));
                     }
+                    if (is_res) {
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
+                        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                        for (int tp = 0; tp < NTP; ++tp)
-                            acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+                            for (int tp = 0; tp < NTP; ++tp)
+                                acc2[DUAL ? tm : 0][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc2[DUAL ? tm : 0][tp], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                            for (int tp = 0; tp < NTP; ++tp)
+                                acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -333,6 +347,43 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 }
             } else {
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = pack8_bf16(v);
+            }
+        }
+    }
+    if (res_fused) {
+        // ---- second output: res = res_conv(x) + bias2 (no GroupNorm fold, no activation, no statistics), bf16 NHWC ----
+        for (int pass = 0; pass < 256 / PXH; ++pass) {
+            __syncthreads();
+            if ((wq * TPW) / PXH == pass) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tp = 0; tp < NTP; ++tp) {
+                        const int px = (wq * TPW) % PXH + tp * 32 + (lane & 31);
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
+                            const f32x16_t& a2 = acc2[DUAL ? tm : 0][tp];
+                            *reinterpret_cast<float4*>(&stage[px * SL + f]) = make_float4(a2[rg * 4 + 0], a2[rg * 4 + 1], a2[rg * 4 + 2], a2[rg * 4 + 3]);
+                        }
+                    }
+            }
+            __syncthreads();
+            for (int it = tid; it < PXH * nf8; it += HC_THREADS) {
+                const int px = it / nf8;
+                const int f8 = (it - px * nf8) * 8;
+                const int slot = pass * PXH + px;
+                if (slot >= nslots) continue;
+                const int r = fdiv_small(slot, inv_tw), cc = slot - r * tw;
+                const int y = y0 + r, x = x0 + cc;
+                if (y >= p.H || x >= p.W) continue;
+                const int f = fbase + f8;
+                if (f >= p.nfeat) continue;
+                const float4 a = *reinterpret_cast<const float4*>(&stage[px * SL + f8]);
+                const float4 d = *reinterpret_cast<const float4*>(&stage[px * SL + f8 + 4]);
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias2 + f), b1 = *reinterpret_cast<const float4*>(p.bias2 + f + 4);
+                const float v[8] = {a.x + b0.x, a.y + b0.y, a.z + b0.z, a.w + b0.w, d.x + b1.x, d.y + b1.y, d.z + b1.z, d.w + b1.w};
+                *reinterpret_cast<uint4*>(p.out2 + (long long)b * p.out2_bstride + ((long long)(y + 1) * p.Wp + (x + 1)) * p.out2_ld + f) = pack8_bf16(v);
             }
         }
     }

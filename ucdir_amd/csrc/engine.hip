@@ -78,6 +78,7 @@ struct ConvW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
     int rows_pad = 0, Kpad = 0, ntaps = 0, cin = 0, cout = 0, TM = 128; bool fold = false;
     bf16_t* Aup = nullptr; int Kup = 0;     // Upsample convs: parity-decomposed 2x2 weights [4][rows_pad][4*cin]
+    bf16_t* A10 = nullptr; float* bias_res = nullptr;   // conv1 + the block's res_conv as a 10th tap (64-row tiles only)
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -248,24 +249,24 @@ static void choose_tile(int H, int W, int& th, int& tw) {
         }
 }
 
-template <int TM>
+template <int TM, bool DUAL = false>
 static void launch_halo(const GemmP& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, hc_lds_bytes<TM>()));
+        HIPC(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TM, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, hc_lds_bytes<TM>()));
         attr_done = true;
     }
     const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1);
     if (g_prof.on) {
-        ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
+        ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0) + (DUAL ? 2 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
         e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
-        hipLaunchKernelGGL((conv3x3_halo_kernel<TM>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<TM, DUAL>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
         HIPC(hipEventRecord(e.e1, st));
         g_prof.entries.push_back(e);
     } else {
-        hipLaunchKernelGGL((conv3x3_halo_kernel<TM>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<TM, DUAL>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
     }
     HIPC(hipGetLastError());
 }
@@ -273,8 +274,10 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
 static bool g_use_halo = true;
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
-static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
-                     bool want_stats, hipStream_t st, float* nchw_out = nullptr, int crop_h = 0, int crop_w = 0) {
+// res_out != nullptr asks for the block's res_conv output from the same launch; returns true if it was produced
+static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
+                     bool want_stats, hipStream_t st, float* nchw_out = nullptr, int crop_h = 0, int crop_w = 0,
+                     Act* res_out = nullptr) {
     GemmP p; zero_gemm(p);
     const int cin = x0.C + (x1 ? x1->C : 0);
     require(cin == w.cin, "run_conv: channel mismatch");
@@ -332,7 +335,14 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         tm_run = 64; p.rowtiles = w.rows_pad / 64;
         if (want_stats) { p.npart = p.tiles * p.rowtiles; require(p.npart <= y.npart_cap, "run_conv: partial buffer too small"); }
     }
-    if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else launch_halo<64>(p, st); }
+    static const bool fuse_res = !getenv("UCDIR_NO_FUSED_RES");
+    bool did_res = false;
+    if (halo && !upph && tm_run == 64 && w.TM == 64 && w.A10 && res_out && fuse_res) {
+        p.A = w.A10; p.a_ld = 10 * cin; p.res_fused = 1; p.bias2 = w.bias_res;
+        p.out2 = res_out->p; p.out2_bstride = res_out->bstride(); p.out2_ld = res_out->C;
+        did_res = true;
+    }
+    if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else if (did_res) launch_halo<64, true>(p, st); else launch_halo<64>(p, st); }
     else launch_cgemm(p, w.TM, EPI_STD, st);
 #ifdef UCDIR_TIMING
     if (halo) {
@@ -345,6 +355,7 @@ static void run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         fprintf(stderr, "\n");
     }
 #endif
+    return did_res;
 }
 
 // halo-tile AKGM kernel (akgm_halo.hip.h): 8 / 16 / 32 / 64 channels per group
@@ -695,9 +706,18 @@ static void finalize_weights(ucdir_ctx* c) {
                                  W_(c, r + "conv1.bias", d.cout).data(), W_(c, r + "norm1.weight", d.cin).data(),
                                  W_(c, r + "norm1.bias", d.cin).data(), d.cout, d.cin, 3);
             w.has_res = d.cin != d.cout;
-            if (w.has_res)
+            if (w.has_res) {
                 w.resconv = upload_conv(c->wpool, W_(c, r + "res_conv.weight", (size_t)d.cout * d.cin).data(),
                                         W_(c, r + "res_conv.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cin, 1);
+                if (w.conv.TM == 64 && d.cin % 64 == 0 && w.conv.Kpad == 9 * d.cin) {
+                    // res_conv rides in conv1's launch as a 10th tap (conv3x3_halo_kernel<64>): x is read once
+                    PackedConv P = pack_conv(W_(c, r + "conv1.weight", (size_t)d.cout * d.cin * 9).data(), nullptr,
+                                             W_(c, r + "norm1.weight", d.cin).data(), W_(c, r + "norm1.bias", d.cin).data(),
+                                             d.cout, d.cin, 3, 64);
+                    w.conv.A10 = c->wpool.upload(pack_conv_res10(P, W_(c, r + "res_conv.weight", (size_t)d.cout * d.cin).data()));
+                    w.conv.bias_res = w.resconv.bias;
+                }
+            }
             w.sp = upload_akgm(c->wpool, W_(c, r + "spdyconv.weight", (size_t)8 * d.cout * (d.cout / 8) * 9).data(),
                                W_(c, r + "spdyconv.bias", (size_t)8 * d.cout).data(), W_(c, r + "norm2.weight", d.cout).data(),
                                W_(c, r + "norm2.bias", d.cout).data(), d.cout);
@@ -827,9 +847,9 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
             const Act* x0 = cur; const Act* x1 = nullptr;
             if (d.skip_c) { x1 = skips.back(); skips.pop_back(); require(x1->C == d.skip_c, "skip channel mismatch"); }
             // h1 = swish(conv1(GN1(cat[x0,x1])))
-            run_conv(w.conv, *x0, x1, r.h1, COLS_S1, 1, nullptr, true, st);
+            const bool res_done = run_conv(w.conv, *x0, x1, r.h1, COLS_S1, 1, nullptr, true, st, nullptr, 0, 0, w.has_res ? &r.res : nullptr);
             const Act* res = x0;
-            if (w.has_res) { run_conv(w.resconv, *x0, x1, r.res, COLS_S1, 0, nullptr, false, st); res = &r.res; }
+            if (w.has_res) { if (!res_done) run_conv(w.resconv, *x0, x1, r.res, COLS_S1, 0, nullptr, false, st); res = &r.res; }
             Act& bo = d.attn ? r.bo : r.out;
             run_akgm(w.sp, r.h1, r.G, c->attw + (size_t)w.block_index * B * 8, *res, bo, st);
             if (d.attn) run_attention(w.qkv, w.outp, bo, r.out, c->attn, st);

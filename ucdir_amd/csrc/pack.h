@@ -73,6 +73,20 @@ static inline PackedConv pack_conv(const float* w, const float* bias, const floa
     return P;
 }
 
+// conv1 of a residual block whose res_conv is fused into it (conv3x3_halo_kernel<64>): the packed rows get a 10th
+// tap block holding the 1x1 res_conv weights (plain bf16, no GroupNorm fold: res_conv sees the raw input).
+// P: pack_conv(conv1) with Kpad == 9*cin; wres: [cout][cin].  Returns [rows_pad][10*cin].
+static inline std::vector<bf16_t> pack_conv_res10(const PackedConv& P, const float* wres) {
+    const int cin = P.cin, K10 = 10 * cin;
+    std::vector<bf16_t> A((size_t)P.rows_pad * K10, 0);
+    for (int o = 0; o < P.rows_pad; ++o) {
+        for (int k = 0; k < 9 * cin; ++k) A[(size_t)o * K10 + k] = P.A[(size_t)o * P.Kpad + k];
+        if (o < P.cout)
+            for (int c = 0; c < cin; ++c) A[(size_t)o * K10 + 9 * cin + c] = f2bf(wres[(size_t)o * cin + c]);
+    }
+    return A;
+}
+
 struct PackedAkgm {
     std::vector<bf16_t> A;        // [8 groups][C rows][Kpad]
     std::vector<float> bias;      // [8C] original order
