@@ -326,8 +326,13 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         const int f = fbase + f8;
         if (f >= p.nfeat) continue;
         int cls = 0;
-        long long opos = cp;
-        if (MODE != MODE_PLAIN) {
+        long long opos = cp, rpos = cp;
+        if (MODE == MODE_PLAIN) {
+            if (p.plain_w) {
+                const int y = cp / p.plain_w, x = cp - y * p.plain_w;
+                opos = rpos = (long long)(y + 1) * (p.plain_w + 2) + x + 1;
+            }
+        } else {
             int y = cp / p.Wp, x = cp - y * p.Wp;
             if (!(y >= 1 && y <= p.H && x >= 1 && x <= p.W)) continue;
             cls = (y == 1 ? 0 : (y == p.H ? 2 : 1)) * 3 + (x == 1 ? 0 : (x == p.W ? 2 : 1));
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             for (int i = 0; i < 8; ++i) v[i] = (p.act == 1) ? silu_f(v[i]) : fmaxf(0.2f * v[i], v[i]);
         }
         if (p.res) {
-            const bf16_t* rp = p.res + (long long)b * p.res_bstride + (long long)cp * p.res_ld + p.res_coff + f;
+            const bf16_t* rp = p.res + (long long)b * p.res_bstride + rpos * p.res_ld + p.res_coff + f;
             uint4 rv = *reinterpret_cast<const uint4*>(rp);
             const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
 #pragma unroll

@@ -119,6 +119,7 @@ struct GemmP {
     float* partials; int npart;
     stat_t* stats_out;                      // != nullptr: add this launch's partial sums here (stat_add) instead of `partials`
     // fused res_conv (conv3x3_halo_kernel<64>): A carries a 10th tap = the block's 1x1 res_conv; second bf16 NHWC output
+    int plain_w;                            // COLS_PLAIN only, > 0: column n is pixel (n / plain_w, n % plain_w); output and residual use the zero-bordered layout
     int res_fused; bf16_t* out2; long long out2_bstride; int out2_ld; const float* bias2;
     // AKGM
     const float* G; long long g_bstride;   // guide branch, compact [B][H*W][8]

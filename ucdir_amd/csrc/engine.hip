@@ -464,7 +464,6 @@ struct AttnBufs {
     float* S = nullptr;      // [B][N][Npad]
     bf16_t* P = nullptr;     // [B][N][Npad]
     bf16_t* Vt = nullptr;    // [B][C][Npad]
-    bf16_t* O = nullptr;     // [B][N][C]
     int N = 0, Npad = 0, C = 0, B = 0;
 };
 
@@ -474,7 +473,25 @@ static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C) {
     a.S = (float*)pool.alloc((size_t)B * N * a.Npad * 4);
     a.P = (bf16_t*)pool.alloc((size_t)B * N * a.Npad * 2);
     a.Vt = (bf16_t*)pool.alloc((size_t)B * C * a.Npad * 2);
-    a.O = (bf16_t*)pool.alloc((size_t)B * N * C * 2);
+}
+
+// SelfAttention algebra (model/ucdir.py:165-182): out(softmax(.) v) = softmax(.) (W_o v), and v = W_v GN(x) is
+// itself a 1x1 conv, so the value rows of the qkv weight are replaced by W_o W_v (fp64 product, rounded to bf16
+// once): the attention-weighted sum then IS the projected output and the separate out-projection GEMM disappears
+// (bias, residual and statistics move into the P V epilogue).
+static std::vector<float> fold_out_into_v(const float* wqkv, const float* wout, int C) {
+    std::vector<float> w(wqkv, wqkv + (size_t)3 * C * C);
+    std::vector<double> row(C);
+    for (int o = 0; o < C; ++o) {
+        for (int i = 0; i < C; ++i) row[i] = 0.0;
+        for (int m = 0; m < C; ++m) {
+            const double a = wout[(size_t)o * C + m];
+            const float* wv = wqkv + ((size_t)2 * C + m) * C;
+            for (int i = 0; i < C; ++i) row[i] += a * (double)wv[i];
+        }
+        for (int i = 0; i < C; ++i) w[((size_t)2 * C + o) * C + i] = (float)row[i];
+    }
+    return w;
 }
 
 // SelfAttention (model/ucdir.py:165-182): y = out(softmax(q^T k / sqrt(C)) v) + x
@@ -519,7 +536,8 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         else if (Npad <= 64 * 4 * 6) hipLaunchKernelGGL((softmax_kernel<6>), g, dim3(256), 0, st, a.S, a.P, rows, N, Npad);
         else hipLaunchKernelGGL((softmax_kernel<0>), g, dim3(256), 0, st, a.S, a.P, rows, N, Npad);
     }
-    // 5. O[i][c] = sum_j P[i][j] V[c][j]   (rows = channels, cols = queries, K = Npad)
+    // 5. y[i][c] = sum_j P[i][j] V'[c][j] + bias[c] + x[i][c]   (rows = channels, cols = queries, K = Npad; V' = W_o V,
+    //    see fold_out_into_v) written straight into the zero-bordered NHWC output, with its GroupNorm statistics
     {
         GemmP p; zero_gemm(p);
         p.A = a.Vt; p.a_bstride = (long long)C * Npad; p.a_ld = Npad; p.a_rows = C;
@@ -527,19 +545,8 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         p.cols_mode = COLS_PLAIN; p.H = 1; p.W = N; p.Wp = N; p.p0 = 0; p.pn = N;
         p.ntaps = 1; p.cg = Npad; p.cpt = Npad / 8; p.nk = Npad / CG_BK;
         p.tiles = (N + CG_TP - 1) / CG_TP; p.rowtiles = C / 128; p.nbatch = B;
-        p.out = a.O; p.out_bstride = (long long)N * C; p.out_ld = C; p.nfeat = C;
-        launch_cgemm(p, 128, EPI_STD, st);
-    }
-    // 6. y = conv1x1(O) + bias + x
-    {
-        GemmP p; zero_gemm(p);
-        p.A = wout.A; p.a_ld = wout.Kpad; p.a_rows = wout.rows_pad;
-        p.B0 = a.O; p.b0_bstride = (long long)N * C; p.ld0 = C; p.c0 = C; p.in_compact = 1;
-        p.cols_mode = COLS_S1; p.H = x.H; p.W = x.W; p.Wp = x.W + 2; p.Hi = x.H; p.Wi = x.W; p.Wpi = p.Wp;
-        p.p0 = p.Wp + 1; p.pn = (x.H - 1) * p.Wp + x.W;
-        p.ntaps = 1; p.cg = C; p.cpt = C / 8; p.nk = C / CG_BK;
-        p.tiles = (p.pn + CG_TP - 1) / CG_TP; p.rowtiles = wout.rows_pad / 128; p.nbatch = B;
         p.bias = wout.bias;
+        p.plain_w = x.W;
         p.res = x.p; p.res_bstride = x.bstride(); p.res_ld = C;
         p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
         p.npart = p.tiles * p.rowtiles;
@@ -734,7 +741,9 @@ static void finalize_weights(ucdir_ctx* c) {
             }
             if (d.attn) {
                 const std::string a = d.name + ".attn.";
-                w.qkv = upload_conv(c->wpool, W_(c, a + "qkv.weight", (size_t)3 * d.cout * d.cout).data(), nullptr,
+                const std::vector<float> wf = fold_out_into_v(W_(c, a + "qkv.weight", (size_t)3 * d.cout * d.cout).data(),
+                                                              W_(c, a + "out.weight", (size_t)d.cout * d.cout).data(), d.cout);
+                w.qkv = upload_conv(c->wpool, wf.data(), nullptr,
                                     W_(c, a + "norm.weight", d.cout).data(), W_(c, a + "norm.bias", d.cout).data(),
                                     3 * d.cout, d.cout, 1);
                 w.outp = upload_conv(c->wpool, W_(c, a + "out.weight", (size_t)d.cout * d.cout).data(),
@@ -1106,7 +1115,8 @@ int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int3
     Act ax = act_from_nchw(pool, x, B, C, H, W, st, true);
     Act out = make_act(pool, B, H, W, C);
     AttnBufs ab; alloc_attn(pool, ab, B, H * W, C);
-    ConvW wq = upload_conv(pool, wqkv_host, nullptr, gamma_host, beta_host, 3 * C, C, 1);
+    const std::vector<float> wf = fold_out_into_v(wqkv_host, wout_host, C);
+    ConvW wq = upload_conv(pool, wf.data(), nullptr, gamma_host, beta_host, 3 * C, C, 1);
     ConvW wo = upload_conv(pool, wout_host, bout_host, nullptr, nullptr, C, C, 1);
     run_attention(wq, wo, ax, out, ab, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
