@@ -371,9 +371,13 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     // A/B); for 16 per group it measured +7 % slower (exposed reload of unit 1), so it stays opt-in (UCDIR_PRE16)
     static const bool use_pre = !getenv("UCDIR_NO_PRE"), use_pre16 = getenv("UCDIR_PRE16") != nullptr;
     const bool pre = use_pre && w.Apre != nullptr && (w.cg == 8 || use_pre16);
-    static float* tcbuf = nullptr; static size_t tccap = 0;
+    // fold-table scratch, one per stream: launches on different streams (two contexts side by side) must not share it
+    struct TcBuf { float* p = nullptr; size_t cap = 0; };
+    static std::map<hipStream_t, TcBuf> tcbufs;
+    TcBuf& tb = tcbufs[st];
     const size_t need = (size_t)y.B * 9 * 8 * w.C * sizeof(float);
-    if (need > tccap) { if (tcbuf) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tcbuf); } HIPC(hipMalloc((void**)&tcbuf, need)); tccap = need; }
+    if (need > tb.cap) { if (tb.p) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tb.p); } HIPC(hipMalloc((void**)&tb.p, need)); tb.cap = need; }
+    float* tcbuf = tb.p;
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
     hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf);
     AkgmHP p;
