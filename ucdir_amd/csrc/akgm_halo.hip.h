@@ -19,7 +19,7 @@ struct AkgmHP {
     const bf16_t* h; long long h_bstride;      // swish(conv1), zero-bordered NHWC, C channels
     int C, cg, H, W, Wp, th, tw, tiles_x, tiles_y, nbatch;
     const stat_t* stats; double inv_count;
-    const float* Tc;                           // [B][9][8C]: bias + Tb - mean*rstd*Tg (akgm_tc_kernel), original row order
+    const float* Tc;                           // [B][9][8C]: (bias + Tb)/rstd - mean*Tg (akgm_tc_kernel), original row order
     const float* G; long long g_bstride; const float* attw;
     const bf16_t* res; long long res_bstride;
     bf16_t* out; long long out_bstride;
@@ -33,15 +33,18 @@ struct AkgmHP {
 #define AH_SL 20                                 // floats per pixel in the output stage (16 features + pad)
 #define AH_LDS (2 * HC_HALO_BYTES + 2 * AH_ASTAGE + 128 + 9 * AH_TM * 4)
 
-// Tc[b][cls][o] = bias[o] + Tb[cls][o] - mean_b * rstd_b * Tg[cls][o]   (once per launch; grid (9, B))
+// Tc[b][cls][o] = (bias[o] + Tb[cls][o]) / rstd_b - mean_b * Tg[cls][o]   (once per launch; grid (9, B)): the GroupNorm
+// fold constant of row o DIVIDED by rstd, so rstd is applied once after the modulation sum,
+//   rstd * sum_s att_s (conv_s + Tc_s) = sum_s att_s (rstd conv_s + fold_s),
+// and akgm_pre.hip.h can start its accumulators at Tc instead of zero
 __global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_count, const float* __restrict__ bias,
                                const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc) {
     const int b = blockIdx.y, cls = blockIdx.x;
     float mean, rstd;
     mean_rstd(stat_val(stats[b * 2]), stat_val(stats[b * 2 + 1]), inv_count, mean, rstd);
-    const float mr = mean * rstd;
+    const float inv = 1.0f / rstd;
     for (int o = threadIdx.x; o < n; o += blockDim.x)
-        Tc[((long long)b * 9 + cls) * n + o] = bias[o] + Tb[(long long)cls * n + o] - mr * Tg[(long long)cls * n + o];
+        Tc[((long long)b * 9 + cls) * n + o] = (bias[o] + Tb[(long long)cls * n + o]) * inv - mean * Tg[(long long)cls * n + o];
 }
 
 __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p) {
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
                     float sa = 0.f, sb = 0.f;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) { sa += att[tp][s] * acc[tm][tp][8 * q + s]; sb += att[tp][s] * tcv[s]; }
-                    stage[px * AH_SL + floc] = valid[tp] ? (rstd * sa + sb) : 0.f;
+                    stage[px * AH_SL + floc] = valid[tp] ? rstd * (sa + sb) : 0.f;
                 }
             }
         }

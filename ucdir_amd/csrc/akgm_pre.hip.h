@@ -156,13 +156,22 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
         const unsigned char* Au = abuf + ((CG == 8) ? u * L::A_UNIT : 0);
         const float* tcu = tcs + ((CG == 8) ? u * 9 * 128 : 0);
 
+        // accumulators start at the fold constants Tc[cls(pixel)][row] (akgm_tc_kernel: already divided by rstd) instead
+        // of zero: registers 0..15 of a tile = features floc0, floc0 + 1 x 8 sets = 16 consecutive floats of the table
         f32x16_t acc[2][2];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tp = 0; tp < 2; ++tp) {
+            const float* tc = tcu + (cls[tp] < 0 ? 0 : cls[tp]) * 128;
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
+            for (int tm = 0; tm < 2; ++tm) {
+                const float* t16 = tc + 8 * (4 * (wm * 2 + tm) + 2 * hh);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(t16 + 4 * g);
+                    acc[tm][tp][4 * g + 0] = c4.x; acc[tm][tp][4 * g + 1] = c4.y; acc[tm][tp][4 * g + 2] = c4.z; acc[tm][tp][4 * g + 3] = c4.w;
+                }
+            }
+        }
 
         asm volatile("" : "+v"(hp0[0]), "+v"(hp0[1]));                  // no hoisting of per-step addresses out of the unit loop (spills)
         const int ch16 = 2 * u + ((CG == 8) ? wm : hh);                // 16-byte chunk of the halo row this lane's k half reads
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
                 bfr[buf][tp] = *reinterpret_cast<const bf16x8_t*>(halo + hp * 64 + ((ch16 ^ ((hp >> 2) & 3)) << 4));
             }
         };
+        __builtin_amdgcn_sched_barrier(0);          // the table reads above stay out of the pipelined region below
         load_frags(0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -209,7 +219,6 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
             const int px = wq * 64 + tp * 32 + (lane & 31);
-            const float* tc = tcu + (cls[tp] < 0 ? 0 : cls[tp]) * 128;
             const int gsw = (px >> 2) & 3;
             float att[8];
             {
@@ -219,17 +228,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const int t32 = wm * 2 + tm;
-                const int floc0 = 4 * t32 + 2 * hh;                  // this lane: features floc0, floc0 + 1
                 float v[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const float4 c0 = *reinterpret_cast<const float4*>(tc + 8 * (floc0 + q));
-                    const float4 c1 = *reinterpret_cast<const float4*>(tc + 8 * (floc0 + q) + 4);
-                    const float tcv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                    float sa = 0.f, sb = 0.f;
+                    float sa = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) { sa += att[s] * acc[tm][tp][8 * q + s]; sb += att[s] * tcv[s]; }
-                    v[q] = cls[tp] >= 0 ? (rstd * sa + sb) : 0.f;
+                    for (int s = 0; s < 8; ++s) sa += att[s] * acc[tm][tp][8 * q + s];
+                    v[q] = cls[tp] >= 0 ? rstd * sa : 0.f;
                 }
                 *reinterpret_cast<float2*>(&stage[px * 16 + ((t32 ^ gsw) << 2) + 2 * hh]) = make_float2(v[0], v[1]);
             }
