@@ -27,9 +27,12 @@ def bench_name(k):
         return f"cgemm<{tm},akgm>" if epi == 1 else f"cgemm<{tm},std,{MODE[mode]}>"
     if k.startswith("akgm_halo_kernel"):
         return "akgm_halo"
-    m = re.search(r"conv3x3_halo_kernel<(\d+)>", k)
+    if "akgm_pre_kernel" in k:
+        return "akgm_pre"
+    m = re.search(r"conv3x3_halo_kernel<(\d+)(?:, (true|false))?>", k)
     if m:
-        return f"conv3x3_halo<{m.group(1)}>"      # also carries the parity-decomposed Upsample launches
+        # <128> / <64> also carry the parity-decomposed Upsample launches; <64, true> = conv1 + fused res_conv
+        return f"conv3x3_halo<{m.group(1)}>" + ("+res" if m.group(2) == "true" else "")
     return None
 
 
