@@ -23,8 +23,7 @@ struct AkgmHP {
     const float* G; long long g_bstride; const float* attw;
     const bf16_t* res; long long res_bstride;
     bf16_t* out; long long out_bstride;
-    float* partials; int npart;
-    stat_t* stats_out;                         // != nullptr: add the partial sums here (stat_add) instead of `partials`
+    stat_t* stats_out;                         // (sum, sum of squares) accumulators of the output (stat_add)
     unsigned long long* dbg;
 };
 
@@ -41,7 +40,9 @@ __global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_coun
                                const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc) {
     const int b = blockIdx.y, cls = blockIdx.x;
     float mean, rstd;
-    mean_rstd(stat_val(stats[b * 2]), stat_val(stats[b * 2 + 1]), inv_count, mean, rstd);
+    double S, Q;
+    stat_read(stats, nullptr, b, S, Q);
+    mean_rstd(S, Q, inv_count, mean, rstd);
     const float inv = 1.0f / rstd;
     for (int o = threadIdx.x; o < n; o += blockDim.x)
         Tc[((long long)b * 9 + cls) * n + o] = (bias[o] + Tb[(long long)cls * n + o]) * inv - mean * Tg[(long long)cls * n + o];
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     float rstd;
     {
         float mean_unused;
-        mean_rstd(stat_val(p.stats[b * 2]), stat_val(p.stats[b * 2 + 1]), p.inv_count, mean_unused, rstd);
+        double S, Q;
+        stat_read(p.stats, nullptr, b, S, Q);
+        mean_rstd(S, Q, p.inv_count, mean_unused, rstd);
     }
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
-    if (p.partials || p.stats_out) {
+    if (p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
         __syncthreads();
@@ -285,11 +288,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         if (tid == 0) {
             float t1 = 0.f, t2 = 0.f;
             for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2 += scal[3 + w * 2]; }
-            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2);
-            else {
-                float* pp = p.partials + ((long long)b * p.npart + (long long)(ty * p.tiles_x + tx) * nsec + sec) * 2;
-                pp[0] = t1; pp[1] = t2;
-            }
+            stat_add(p.stats_out, b, t1, t2);
         }
     }
 }

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
     float rstd;
     {
         float mean_unused;
-        mean_rstd(stat_val(p.stats[b * 2]), stat_val(p.stats[b * 2 + 1]), p.inv_count, mean_unused, rstd);
+        double S, Q;
+        stat_read(p.stats, nullptr, b, S, Q);
+        mean_rstd(S, Q, p.inv_count, mean_unused, rstd);
     }
     // ---- per-lane pixel constants (K loop / phase 1) ---------------------------------------------------
     int hp0[2], cls[2];                                                // cls: border class, or -1 for a pixel outside the image / tile
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
-    if (p.partials || p.stats_out) {
+    if (p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
         if (lane == 0) { scal[2 + wave * 2] = s1; scal[3 + wave * 2] = s2; }
@@ -273,11 +275,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
         if (tid == 0) {
             float t1 = 0.f, t2 = 0.f;
             for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2 += scal[3 + w * 2]; }
-            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2);
-            else {
-                float* pp = p.partials + ((long long)b * p.npart + (long long)(ty * p.tiles_x + tx) * nsec + sec) * 2;
-                pp[0] = t1; pp[1] = t2;
-            }
+            stat_add(p.stats_out, b, t1, t2);
         }
     }
 }

@@ -93,9 +93,8 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     if (tid == 0) {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
-            stat_t Si = p.stats0[b * 2], Qi = p.stats0[b * 2 + 1];
-            if (p.stats1) { Si += p.stats1[b * 2]; Qi += p.stats1[b * 2 + 1]; }
-            const double S = stat_val(Si), Q = stat_val(Qi);
+            double S, Q;
+            stat_read(p.stats0, p.stats1, b, S, Q);
             double m = S * p.inv_count;
             double var = Q * p.inv_count - m * m;
             if (var < 0) var = 0;
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
         }
     }
-    if (p.partials || p.stats_out) {
+    if (p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             s1 += __shfl_xor(s1, off);
@@ -406,11 +405,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         if (tid == 0) {
             const float t1 = scal[2] + scal[4] + scal[6] + scal[8];
             const float t2 = scal[3] + scal[5] + scal[7] + scal[9];
-            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2);
-            else {
-                float* pp = p.partials + ((long long)b * p.npart + (long long)tcol * p.rowtiles + rowtile) * 2;
-                pp[0] = t1; pp[1] = t2;
-            }
+            stat_add(p.stats_out, b, t1, t2);
         }
     }
 }

@@ -58,15 +58,36 @@ __device__ inline float act_apply(float v, int act) { return act == 1 ? silu_fas
 // integers.  Every producer workgroup adds its fp32 partial with one fire-and-forget integer atomic per value:
 // integer addition is associative, so the result is bit-identical whatever order the workgroups retire in (an
 // fp64 atomic would not be), nobody waits on anything, and the per-activation reduction launch
-// (stats_finalize_kernel, 69 per forward) disappears.  Resolution 1e-6 absolute against sums of 1e3..1e7;
+// (69 per forward) disappears.  Resolution 1e-6 absolute against sums of 1e3..1e7;
 // range +-8.8e12.  The accumulators of all activations sit in one slab that forward() zeroes with one memset.
+// Device-scope atomics on one address serialise at ~150 ns each on this chip (10,368 workgroups on 32 addresses
+// cost a short kernel 47 us), so every sample has UCDIR_STAT_SLOTS accumulator pairs, a workgroup adds to slot
+// blockIdx.x % SLOTS and readers sum the slots (integers: still order-independent).  Layout [B][SLOTS][2].
 typedef long long stat_t;
 #define UCDIR_STAT_SCALE 1048576.0
+#define UCDIR_STAT_SLOTS 16
 __device__ __forceinline__ double stat_val(stat_t v) { return (double)v * (1.0 / UCDIR_STAT_SCALE); }
 __device__ __forceinline__ stat_t stat_fx(double v) { return __double2ll_rn(v * UCDIR_STAT_SCALE); }
-__device__ __forceinline__ void stat_add(stat_t* dst, float t1, float t2) {      // call from ONE thread of the workgroup
+__device__ __forceinline__ void stat_add(stat_t* stats, int b, float t1, float t2) {      // call from ONE thread of the workgroup
+    stat_t* dst = stats + ((long long)b * UCDIR_STAT_SLOTS + (blockIdx.x % UCDIR_STAT_SLOTS)) * 2;
     (void)__hip_atomic_fetch_add(dst, stat_fx((double)t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)__hip_atomic_fetch_add(dst + 1, stat_fx((double)t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (sum, sum of squares) of sample b, optionally of two tensors together (channel concatenation)
+__device__ __forceinline__ void stat_read(const stat_t* s0, const stat_t* s1, int b, double& S, double& Q) {
+    stat_t a = 0, q = 0;
+#pragma unroll
+    for (int k = 0; k < UCDIR_STAT_SLOTS; ++k) {
+        a += s0[((long long)b * UCDIR_STAT_SLOTS + k) * 2]; q += s0[((long long)b * UCDIR_STAT_SLOTS + k) * 2 + 1];
+        if (s1) { a += s1[((long long)b * UCDIR_STAT_SLOTS + k) * 2]; q += s1[((long long)b * UCDIR_STAT_SLOTS + k) * 2 + 1]; }
+    }
+    S = stat_val(a); Q = stat_val(q);
+}
+// direct (non-atomic) write of a sample's totals: slot 0 carries them, the other slots are cleared
+__device__ __forceinline__ void stat_store(stat_t* stats, int b, double S, double Q) {
+    stat_t* d = stats + (long long)b * UCDIR_STAT_SLOTS * 2;
+    d[0] = stat_fx(S); d[1] = stat_fx(Q);
+    for (int k = 2; k < 2 * UCDIR_STAT_SLOTS; ++k) d[k] = 0;
 }
 
 // Activation tensor in HBM: zero-bordered NHWC bf16, [B][H+2][W+2][C].  The one-pixel zero
@@ -75,10 +96,7 @@ __device__ __forceinline__ void stat_add(stat_t* dst, float t1, float t2) {     
 struct Act {
     bf16_t* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
-    stat_t* stats = nullptr;       // [B][2] (sum, sum of squares) over the valid region, fixed point (stat_val)
-    float* partials = nullptr;     // [B][npart][2] per-workgroup partial sums
-    int npart = 0;                 // partial sums written by the last producer
-    int npart_cap = 0;             // capacity of `partials`
+    stat_t* stats = nullptr;       // [B][SLOTS][2] (sum, sum of squares) over the valid region, fixed point (stat_read)
     __host__ __device__ int Hp() const { return H + 2; }
     __host__ __device__ int Wp() const { return W + 2; }
     long long bstride() const { return (long long)(H + 2) * (W + 2) * C; }
@@ -116,8 +134,7 @@ struct GemmP {
     int out_nchw; int crop_h, crop_w;   // final conv: fp32 NCHW (B, nfeat, crop_h, crop_w)
     int shuffle_c;                      // > 0: ConvTranspose2d(2,2): feature f = q*shuffle_c + o goes to pixel (2y+q/2, 2x+q%2), channel o
     int nfeat;               // valid output features (rows) in total
-    float* partials; int npart;
-    stat_t* stats_out;                      // != nullptr: add this launch's partial sums here (stat_add) instead of `partials`
+    stat_t* stats_out;                      // != nullptr: add this launch's (sum, sum of squares) of the output here (stat_add)
     // fused res_conv (conv3x3_halo_kernel<64>): A carries a 10th tap = the block's 1x1 res_conv; second bf16 NHWC output
     int plain_w;                            // COLS_PLAIN only, > 0: column n is pixel (n / plain_w, n % plain_w); output and residual use the zero-bordered layout
     int res_fused; bf16_t* out2; long long out2_bstride; int out2_ld; const float* bias2;

@@ -100,9 +100,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
-            stat_t Si = p.stats0[b * 2], Qi = p.stats0[b * 2 + 1];
-            if (p.stats1) { Si += p.stats1[b * 2]; Qi += p.stats1[b * 2 + 1]; }
-            const double S = stat_val(Si), Q = stat_val(Qi);
+            double S, Q;
+            stat_read(p.stats0, p.stats1, b, S, Q);
             mean_rstd(S, Q, p.inv_count, mean, rstd);
         }
         if (tid == 0) { scal[0] = mean; scal[1] = rstd; }
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
-    if (p.partials || p.stats_out) {
+    if (p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
         __syncthreads();
@@ -400,11 +399,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         if (tid == 0) {
             float t1 = 0.f, t2s = 0.f;
             for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2s += scal[3 + w * 2]; }
-            if (p.stats_out) stat_add(p.stats_out + b * 2, t1, t2s);
-            else {
-                float* pp = p.partials + ((long long)b * p.npart + ((long long)(ty * p.tiles_x + tx) * p.rowtiles + rowtile) * (p.up_phase ? 4 : 1) + par) * 2;
-                pp[0] = t1; pp[1] = t2s;
-            }
+            stat_add(p.stats_out, b, t1, t2s);
         }
     }
 }

@@ -61,12 +61,13 @@ struct DevPool {
         return p;
     }
     // statistics accumulators of every activation in this pool: one slab, zeroed with one memset per forward
-    static constexpr size_t STAT_CAP = 1 << 15;
+    static constexpr size_t STAT_CAP = 1 << 19;      // 4 MB: 128 activations x B = 64 x 16 slots x 2
     stat_t* stat_slab = nullptr; size_t stat_used = 0;
     stat_t* alloc_stats(int B) {
         if (!stat_slab) stat_slab = (stat_t*)alloc(STAT_CAP * sizeof(stat_t), true);
-        if (stat_used + 2 * (size_t)B > STAT_CAP) throw std::runtime_error("DevPool: statistics slab exhausted");
-        stat_t* p = stat_slab + stat_used; stat_used += 2 * (size_t)B;
+        const size_t n = (size_t)2 * UCDIR_STAT_SLOTS * B;
+        if (stat_used + n > STAT_CAP) throw std::runtime_error("DevPool: statistics slab exhausted");
+        stat_t* p = stat_slab + stat_used; stat_used += n;
         return p;
     }
     void zero_stats(hipStream_t st) { if (stat_used) HIPC(hipMemsetAsync(stat_slab, 0, stat_used * sizeof(stat_t), st)); }
@@ -206,33 +207,11 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 static void zero_gemm(GemmP& p) { std::memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.groups_per_wg = 1; }
 
-// only for producers that still write per-workgroup partials (the stem); the GEMM kernels add their partial sums
-// straight into y.stats (stat_add, common.h), which forward() zeroes beforehand
-static void finalize_stats(Act& y, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(y.B), dim3(256), 0, st, y.partials, y.npart, y.stats);
-    HIPC(hipGetLastError());
-}
-
-// npart upper bound for an activation produced by any cgemm configuration (TM >= 64)
-static int npart_for(int H, int W, int C) {
-    const int pn = (H - 1) * (W + 2) + W;
-    const int tiles = (pn + CG_TP - 1) / CG_TP;
-    int rt = (C + 63) / 64;
-    if (C / 16 > rt) rt = C / 16;          // AKGM launches 8*C/128 row tiles
-    int stem_blocks = ((H * W + 255) / 256) * ((C + 63) / 64);
-    int n = tiles * rt;
-    int halo_tiles = ((H + 3) / 4) * ((W + 15) / 16) * rt;     // generous bound for conv3x3_halo tilings
-    if (halo_tiles > n) n = halo_tiles;
-    return n > stem_blocks ? n : stem_blocks;
-}
-
 static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats = true) {
     Act a; a.B = B; a.H = H; a.W = W; a.C = C;
     a.p = (bf16_t*)pool.alloc((size_t)a.elems() * sizeof(bf16_t), true);
     if (with_stats) {
-        a.npart = a.npart_cap = npart_for(H, W, C);
-        a.partials = (float*)pool.alloc((size_t)B * a.npart * 2 * sizeof(float), true);
-        a.stats = pool.alloc_stats(B);
+        a.stats = pool.alloc_stats(B);       // (sum, sum of squares): producers add into it (stat_add), forward() zeroes the slab
     }
     return a;
 }
@@ -319,8 +298,6 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         }
     }
     if (want_stats) {
-        p.npart = p.tiles * p.rowtiles;
-        require(p.npart <= y.npart_cap, "run_conv: partial buffer too small");
         p.stats_out = y.stats;
     }
 #ifdef UCDIR_TIMING
@@ -333,7 +310,6 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (halo && tm_run == 128 && p.nbatch * p.tiles * p.rowtiles < 256) {
         // too few workgroups for 256 CUs x 2: use 64-row tiles (the packed [rows][K] layout is the same)
         tm_run = 64; p.rowtiles = w.rows_pad / 64;
-        if (want_stats) { p.npart = p.tiles * p.rowtiles; require(p.npart <= y.npart_cap, "run_conv: partial buffer too small"); }
     }
     static const bool fuse_res = !getenv("UCDIR_NO_FUSED_RES");
     bool did_res = false;
@@ -390,9 +366,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
     const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
-    p.npart = p.tiles_x * p.tiles_y * nsec;
-    require(p.npart <= y.npart_cap, "run_akgm_halo: partial buffer too small");
-    p.partials = nullptr; p.stats_out = y.stats;
+    p.stats_out = y.stats;
     const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.dbg = nullptr;
     auto launch = [&]() {
@@ -457,8 +431,6 @@ static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float*
     p.res = res.p; p.res_bstride = res.bstride(); p.res_ld = res.C; p.res_coff = 0;
     p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
-    p.npart = p.tiles * p.rowtiles;
-    require(p.npart <= y.npart_cap, "run_akgm: partial buffer too small");
     p.stats_out = y.stats;
     launch_cgemm(p, TM, EPI_AKGM, st);
 }
@@ -553,8 +525,6 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         p.plain_w = x.W;
         p.res = x.p; p.res_bstride = x.bstride(); p.res_ld = C;
         p.out = y.p; p.out_bstride = y.bstride(); p.out_ld = C; p.nfeat = C;
-        p.npart = p.tiles * p.rowtiles;
-        require(p.npart <= y.npart_cap, "attention: partial buffer too small");
         p.stats_out = y.stats;
         launch_cgemm(p, 128, EPI_STD, st);
     }
@@ -619,7 +589,7 @@ struct LayerW {
     AkgmW sp;
     ConvW qkv, outp;
     float* gw = nullptr;  // guide branch weights
-    float* stem_w = nullptr; float* stem_b = nullptr;
+    bf16_t* stem_w = nullptr;                               // stem_mfma_kernel fragments incl. bias (pack_stem_frags)
     int block_index = -1;
 };
 
@@ -703,8 +673,8 @@ static void finalize_weights(ucdir_ctx* c) {
             std::vector<float> t((size_t)54 * d.cout);
             for (int o = 0; o < d.cout; ++o) for (int ci = 0; ci < 6; ++ci) for (int k = 0; k < 9; ++k)
                 t[(size_t)(k * 6 + ci) * d.cout + o] = sw[((size_t)o * 6 + ci) * 9 + k];
-            w.stem_w = c->wpool.upload(t);
-            w.stem_b = c->wpool.upload(W_(c, d.name + ".bias", (size_t)d.cout));
+            require(d.cout % 64 == 0, "stem: inner_channel must be a multiple of 64");
+            w.stem_w = c->wpool.upload(pack_stem_frags(t, W_(c, d.name + ".bias", (size_t)d.cout), 6, d.cout));
         } else if (d.kind == "down" || d.kind == "up") {
             w.conv = upload_conv(c->wpool, W_(c, d.name + ".conv.weight", (size_t)d.cout * d.cin * 9).data(),
                                  W_(c, d.name + ".conv.bias", d.cout).data(), nullptr, nullptr, d.cout, d.cin, 3);
@@ -846,12 +816,10 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         const LayerW& w = c->lw[li];
         LayerRT& r = c->rt[li];
         if (d.kind == "stem") {
-            dim3 grid((c->Hc * c->Wc + 255) / 256, d.cout / 64, B);
-            r.out.npart = (int)(grid.x * grid.y);
-            hipLaunchKernelGGL((stem_kernel<6, 0>), grid, dim3(256), 0, st, cond, xt, c->H, c->W, c->Hc, c->Wc, d.cout, w.stem_w,
-                               w.stem_b, r.out.p, r.out.partials, r.out.npart);
+            const int tx = (c->Wc + 15) / 16, ty = (c->Hc + 15) / 16;
+            hipLaunchKernelGGL((stem_mfma_kernel<6, 0>), dim3(tx * ty, d.cout / 64, B), dim3(256), 0, st, cond, xt, c->H, c->W,
+                               c->Hc, c->Wc, d.cout, tx, w.stem_w, r.out.p, r.out.stats);
             HIPC(hipGetLastError());
-            finalize_stats(r.out, st);
         } else if (d.kind == "down") {
             run_conv(w.conv, *cur, nullptr, r.out, COLS_DOWN, 0, nullptr, true, st);
         } else if (d.kind == "up") {
@@ -1081,9 +1049,15 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, cout, Ho, Wo);
     HIPC(hipGetLastError());
     std::vector<stat_t> sfx;
-    if (stats_out_host) { sfx.resize((size_t)2 * B); HIPC(hipMemcpyAsync(sfx.data(), out.stats, sizeof(stat_t) * 2 * B, hipMemcpyDeviceToHost, st)); }
+    if (stats_out_host) { sfx.resize((size_t)2 * UCDIR_STAT_SLOTS * B); HIPC(hipMemcpyAsync(sfx.data(), out.stats, sizeof(stat_t) * sfx.size(), hipMemcpyDeviceToHost, st)); }
     HIPC(hipStreamSynchronize(st));
-    for (size_t i = 0; i < sfx.size(); ++i) stats_out_host[i] = (double)sfx[i] / UCDIR_STAT_SCALE;     // fixed point -> sums
+    if (stats_out_host)
+        for (int bb = 0; bb < B; ++bb)
+            for (int q = 0; q < 2; ++q) {                   // fixed-point slots -> (sum, sum of squares)
+                stat_t acc = 0;
+                for (int k = 0; k < UCDIR_STAT_SLOTS; ++k) acc += sfx[((size_t)bb * UCDIR_STAT_SLOTS + k) * 2 + q];
+                stats_out_host[bb * 2 + q] = (double)acc / UCDIR_STAT_SCALE;
+            }
     API_END
 }
 
@@ -1143,7 +1117,7 @@ struct ucdir_predictor {
     std::map<std::string, HostT> host;
     bool finalized = false;
     DevPool wpool, apool;
-    float* in_w = nullptr; float* in_b = nullptr;            // conv1_1 (3 -> 32, VALU kernel), padded to 64 outputs
+    bf16_t* in_w = nullptr;                                  // conv1_1 (3 -> 32 on stem_mfma_kernel, bias included), padded to 64 outputs
     std::map<std::string, ConvW> conv;                       // conv{l}_{1,2}, upv{l}, conv10_1
     int B = 0, H = 0, W = 0, Hc = 0, Wc = 0;
     std::map<std::string, Act> act;
@@ -1185,7 +1159,7 @@ static void predictor_finalize(ucdir_predictor* c) {
         std::vector<float> t((size_t)27 * 64, 0.f);
         for (int o = 0; o < 32; ++o) for (int ci = 0; ci < 3; ++ci) for (int k = 0; k < 9; ++k)
             t[(size_t)(k * 3 + ci) * 64 + o] = w[((size_t)o * 3 + ci) * 9 + k];
-        c->in_w = c->wpool.upload(t); c->in_b = c->wpool.upload(pad_bias(b, 64));
+        c->in_w = c->wpool.upload(pack_stem_frags(t, pad_bias(b, 64), 3, 64));
     }
     struct Spec { const char* name; int cout; std::vector<int> splits; };
     const std::vector<Spec> specs = {
@@ -1249,9 +1223,9 @@ static void predictor_forward(ucdir_predictor* c, const float* x, float* y, hipS
     auto A = [&](const std::string& n) -> Act& { return c->act.at(n); };
     auto CV = [&](const std::string& n) -> const ConvW& { return c->conv.at(n); };
     {   // conv1_1 + LeakyReLU, reading NCHW fp32 with the bottom/right reflect pad (model/ucdir.py:354-361)
-        dim3 grid((c->Hc * c->Wc + 255) / 256, 1, B);
-        hipLaunchKernelGGL((stem_kernel<3, 2>), grid, dim3(256), 0, st, x, x, c->H, c->W, c->Hc, c->Wc, 64, c->in_w, c->in_b,
-                           A("a1").p, (float*)nullptr, 0);
+        const int tx = (c->Wc + 15) / 16, ty = (c->Hc + 15) / 16;
+        hipLaunchKernelGGL((stem_mfma_kernel<3, 2>), dim3(tx * ty, 1, B), dim3(256), 0, st, x, x, c->H, c->W, c->Hc, c->Wc, 64, tx,
+                           c->in_w, A("a1").p, (stat_t*)nullptr);
         HIPC(hipGetLastError());
     }
     run_conv(CV("conv1_2"), A("a1"), nullptr, A("c1"), COLS_S1, 2, nullptr, false, st);

@@ -2,25 +2,6 @@
 #pragma once
 #include "common.h"
 
-// ------------------------------------------------------------------------------------------------
-// GroupNorm statistics: reduce per-workgroup partial sums (written by producer epilogues, fp32)
-// into per-sample (sum, sumsq) in double.  Deterministic (fixed order), one block per sample.
-// ------------------------------------------------------------------------------------------------
-__global__ void stats_finalize_kernel(const float* __restrict__ partials, int npart, stat_t* __restrict__ stats) {
-    const int b = blockIdx.x;
-    const float* pp = partials + (long long)b * npart * 2;
-    double s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < npart; i += blockDim.x) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
-    __shared__ double sh[2][256];
-    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { stats[b * 2] = stat_fx(sh[0][0]); stats[b * 2 + 1] = stat_fx(sh[1][0]); }
-}
-
 // direct statistics of an activation tensor (tests / inputs produced outside the GEMM core)
 __global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int C, stat_t* __restrict__ stats) {
     const int b = blockIdx.x;
@@ -44,7 +25,7 @@ __global__ void act_stats_kernel(const bf16_t* __restrict__ x, int H, int W, int
         if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stats[b * 2] = stat_fx(sh[0][0]); stats[b * 2 + 1] = stat_fx(sh[1][0]); }
+    if (threadIdx.x == 0) stat_store(stats, b, sh[0][0], sh[1][0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,71 +63,127 @@ __global__ void nchw8_to_compact_kernel(const float* __restrict__ src, float* __
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * (n - 1) - i; }
 
 // ------------------------------------------------------------------------------------------------
-// stem: conv3x3(cat[cond, x_t]) 6 -> C0, reading the reference's NCHW fp32 tensors directly
-// (with DY3h.forward's bottom/right reflect pad, model/ucdir.py:303-306) and writing the
-// zero-bordered NHWC bf16 activation + GroupNorm partial sums.  K = 54: VALU, not MFMA.
-// grid (ceil(Hc*Wc/256), C0/64, B), block 256; w: [54][C0] fp32 (k = (ky*3+kx)*6 + ci)
+// Stem on the matrix cores: conv3x3 CIN (6 | 3) -> 64 per block of output channels, straight from the NCHW fp32
+// inputs (bottom/right reflect pad of DY3h.forward / UNetSeeInDark by indexing, model/ucdir.py:303-306,354-361).
+// K = 9 taps x 8 channel slots (CIN real, rest zero) in the tap-pair layout of akgm_pre.hip.h: k16 step j carries
+// tap 2j on lanes 0-31 and tap 2j+1 on lanes 32-63, so a B fragment is the 16 bytes of ONE halo pixel.  The tenth
+// tap slot carries the BIAS (pack_stem_frags: bf16 hi + lo parts against the constant (1, 1, 0, ...)).
+// A workgroup (4 waves) owns a 16x16 pixel tile: the 18x18 halo is gathered once (CIN fp32 loads per pixel -> 8 bf16
+// in LDS, 5 KB), the block's weight fragments (10 KB) are copied to LDS once, wave v takes pixel rows 4v..4v+3 (two
+// 32-pixel MFMA tiles) x 64 channels: 5 steps x 4 MFMAs.  Epilogue: optional LeakyReLU, GroupNorm statistics
+// (stat_add), bf16 NHWC stores through a per-wave LDS tile (16 B per lane, a tile row's 2 KB contiguous).
+// The VALU version of this kernel took 180 us at 288^2 x 16 (v_pk_fma issue bound); this one 60 us + its atomics.
+// grid (tiles_x * tiles_y, C0 / 64, B), block 256
 // ------------------------------------------------------------------------------------------------
-// CIN = 6: DY3h stem (cat[cond, x_t]); CIN = 3: first conv of the predictor (xt unused, LeakyReLU)
 template <int CIN, int ACT>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cond, const float* __restrict__ xt,
-                                                   int H, int W, int Hc, int Wc, int C0,
-                                                   const float* __restrict__ w, const float* __restrict__ bias,
-                                                   bf16_t* __restrict__ out, float* __restrict__ partials, int npart) {
-    __shared__ __attribute__((aligned(16))) float ws[9 * CIN * 64];
+__global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const float* __restrict__ cond, const float* __restrict__ xt,
+                                                           int H, int W, int Hc, int Wc, int C0, int tiles_x,
+                                                           const bf16_t* __restrict__ wfrag,
+                                                           bf16_t* __restrict__ out, stat_t* __restrict__ stats_out) {
+    __shared__ uint4 halo[324];
+    __shared__ uint4 wl[2 * 5 * 64];
     __shared__ float red[8];
-    const int cb = blockIdx.y * 64;
-    const int b = blockIdx.z;
-    for (int i = threadIdx.x; i < 9 * CIN * 64; i += 256) ws[i] = w[(i / 64) * C0 + cb + (i % 64)];
-    __syncthreads();
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    float s1 = 0.f, s2 = 0.f;
-    if (pix < Hc * Wc) {
-        const int y = pix / Wc, x = pix % Wc;
-        float acc[64];
+    __shared__ __attribute__((aligned(16))) unsigned char otile[4 * 32 * 144];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, cb = blockIdx.y;
+    const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
+    {   // halo gather: both pixels of a thread (324 = 256 + 68) have their loads in flight before either is packed
+        float v[2][8];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) acc[c] = bias[cb + c];
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            if (yy < 0 || yy >= Hc) continue;
-            const int ys = reflect_idx(yy, H);
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x + kx - 1;
-                if (xx < 0 || xx >= Wc) continue;
-                const int xs = reflect_idx(xx, W);
+        for (int u = 0; u < 2; ++u) {
+            const int hp = tid + u * 256;
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float* src = ci < 3 ? cond : xt;
-                    const float v = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
-                    const float* wr = ws + ((ky * 3 + kx) * CIN + ci) * 64;
+            for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+            if (hp < 324) {
+                const int hr = hp / 18, hc = hp - hr * 18;
+                const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+                if (yy >= 0 && yy < Hc && xx >= 0 && xx < Wc) {        // zero padding of the (reflect-extended) Hc x Wc image
+                    const int ys = reflect_idx(yy, H), xs = reflect_idx(xx, W);
 #pragma unroll
-                    for (int c = 0; c < 64; c += 4) {
-                        const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
-                        acc[c] += v * w4.x; acc[c + 1] += v * w4.y; acc[c + 2] += v * w4.z; acc[c + 3] += v * w4.w;
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const float* src = ci < 3 ? cond : xt;
+                        v[u][ci] = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
                     }
                 }
             }
         }
-        bf16_t* op = out + (((long long)b * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C0 + cb;
 #pragma unroll
-        for (int c = 0; c < 64; c += 8) {
-            uint4 ov; bf16_t* oh = reinterpret_cast<bf16_t*>(&ov);
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * 256 < 324) halo[tid + u * 256] = pack8_bf16(v[u]);
+    }
+    // this block's weight fragments (10 KB, shared by the four waves) go to LDS once; 40 VGPRs of resident fragments
+    // would cost half the occupancy
+    for (int i = tid; i < 2 * 5 * 64; i += 256)
+        wl[i] = *reinterpret_cast<const uint4*>(wfrag + ((long long)cb * 2 * 5 * 64 + i) * 8);
+    __syncthreads();
+    int hp0[2];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float a = (ACT == 2) ? fmaxf(0.2f * acc[c + k], acc[c + k]) : acc[c + k];
-                oh[k] = f2bf(a); s1 += a; s2 += a * a;
-            }
-            *reinterpret_cast<uint4*>(op + c) = ov;
+    for (int tp = 0; tp < 2; ++tp) {
+        const int slot = tp * 32 + (lane & 31);
+        hp0[tp] = (wv * 4 + (slot >> 4)) * 18 + (slot & 15);
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {                       // not unrolled: hipcc would hoist all 20 fragment reads (80 VGPRs)
+        const int t0 = 2 * j, t1 = (2 * j + 1 > 8) ? 8 : 2 * j + 1;
+        const int sh = hh ? (t1 / 3) * 18 + (t1 % 3) : (t0 / 3) * 18 + (t0 % 3);
+        bf16x8_t af[2], bfr[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const bf16x8_t*>(&wl[(tm * 5 + j) * 64 + lane]);
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            bfr[tp] = *reinterpret_cast<const bf16x8_t*>(&halo[hp0[tp] + sh]);
+            if (j == 4 && hh) bfr[tp] = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0u, 0u, 0u));   // bias slot: (1, 1, 0, ...) x (hi, lo)
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+                acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    unsigned char* ot = otile + wv * (32 * 144);
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {                       // one 32-pixel MFMA tile (two tile rows) per pass
+        {
+            const int slot = lane & 31;
+            const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
+            const bool inb = y < Hc && x < Wc;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = tm * 32 + 8 * g + 4 * hh;
+                    float v[4] = {acc[tm][tp][4 * g + 0], acc[tm][tp][4 * g + 1], acc[tm][tp][4 * g + 2], acc[tm][tp][4 * g + 3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (ACT == 2) v[i] = fmaxf(0.2f * v[i], v[i]);
+                        if (inb) { s1 += v[i]; s2 += v[i] * v[i]; }
+                    }
+                    *reinterpret_cast<uint2*>(ot + slot * 144 + ch * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+                }
+        }
+        // the tile is private to the wave: program order + the compiler's lgkmcnt waits make its writes visible to it
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, slot = idx >> 3, c16 = idx & 7;
+            const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
+            if (y < Hc && x < Wc)
+                *reinterpret_cast<uint4*>(out + (((long long)b * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C0 + cb * 64 + c16 * 8) =
+                    *reinterpret_cast<const uint4*>(ot + slot * 144 + c16 * 16);
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
-    __syncthreads();
-    if (threadIdx.x == 0 && partials) {
-        float* pp = partials + ((long long)b * npart + (long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
-        pp[0] = red[0] + red[2] + red[4] + red[6];
-        pp[1] = red[1] + red[3] + red[5] + red[7];
+    if (stats_out) {
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        if (lane == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid == 0) stat_add(stats_out, b, red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
     }
 }
 
@@ -161,8 +198,10 @@ __global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__
     const int b = blockIdx.z;
     float mean, rstd;
     {
-        double m = stat_val(stats[b * 2]) * inv_count;
-        double var = stat_val(stats[b * 2 + 1]) * inv_count - m * m;
+        double S, Q;
+        stat_read(stats, nullptr, b, S, Q);
+        double m = S * inv_count;
+        double var = Q * inv_count - m * m;
         if (var < 0) var = 0;
         mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
@@ -212,7 +251,11 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restric
     for (int it = threadIdx.x; it < nstep * 64; it += 256)
         *reinterpret_cast<uint4*>(wl + it * 16) = *reinterpret_cast<const uint4*>(wfrag + (long long)it * 8);
     float mean, rstd;
-    mean_rstd(stat_val(stats[b * 2]), stat_val(stats[b * 2 + 1]), inv_count, mean, rstd);
+    {
+        double S, Q;
+        stat_read(stats, nullptr, b, S, Q);
+        mean_rstd(S, Q, inv_count, mean, rstd);
+    }
     const int c8n = C / 8;
     const bf16_t* xb = x + (long long)b * (H + 2) * (W + 2) * C;
     float* gb = reinterpret_cast<float*>(wl + nstep * 1024);          // GN as one FMA: scale = rstd*gamma | shift = beta - mean*rstd*gamma

@@ -167,6 +167,30 @@ static inline std::vector<bf16_t> pack_akgm_pre(const float* wsp, const float* g
     return img;
 }
 
+// A fragments of stem_mfma_kernel (misc.hip.h): [C0/64 blocks][tm 2][k16 step j 5][lane 64][8] bf16; lane = (k half
+// hh = lane >> 5, row = lane & 31): tap 2j + hh, channel slot e (e >= cin zero).  The tenth tap slot (j = 4, hh = 1)
+// carries the BIAS as bf16 hi + lo parts in slots 0 and 1 (the kernel feeds it the constant (1, 1, 0, ...)), so the
+// epilogue has no bias to load or add and the sum is exact to 2^-17.
+// t: [9 * cin][C0] fp32 with k = tap * cin + ci; bias: [C0].
+static inline std::vector<bf16_t> pack_stem_frags(const std::vector<float>& t, const std::vector<float>& bias, int cin, int C0) {
+    const int nb = C0 / 64;
+    std::vector<bf16_t> f((size_t)nb * 2 * 5 * 64 * 8, 0);
+    for (int cb = 0; cb < nb; ++cb)
+        for (int tm = 0; tm < 2; ++tm)
+            for (int j = 0; j < 5; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = cb * 64 + tm * 32 + (lane & 31), tap = 2 * j + (lane >> 5);
+                    bf16_t* d = &f[((((size_t)cb * 2 + tm) * 5 + j) * 64 + lane) * 8];
+                    if (tap > 8) {
+                        const bf16_t hi = f2bf(bias[row]);
+                        d[0] = hi; d[1] = f2bf(bias[row] - bf2f(hi));
+                        continue;
+                    }
+                    for (int e = 0; e < cin; ++e) d[e] = f2bf(t[(size_t)(tap * cin + e) * C0 + row]);
+                }
+    return f;
+}
+
 // A fragments of final_conv_kernel (misc.hip.h): [step = tap * (C/32) + c32][lane][8] bf16 for v_mfma_f32_16x16x32_bf16,
 // lane = (k group g = lane >> 4, row = lane & 15): W[row][c32*32 + g*8 + e][tap], rows >= cout zero.  w: [cout][C][3][3]
 static inline std::vector<bf16_t> pack_final_frags(const float* w, int cout, int C) {
