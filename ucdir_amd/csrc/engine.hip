@@ -845,7 +845,7 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         static const bool fused = !getenv("UCDIR_NO_FUSED_FINAL");
         if (fused && c->fin_w) {
             const dim3 grid((c->Wc + 15) / 16, (c->Hc + 15) / 16, B);
-            const size_t lds = (size_t)324 * (2 * C + 16) + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C;
+            const size_t lds = (size_t)324 * 80 + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C;
             require(lds <= 160 * 1024, "final conv: channel count too large for the fused kernel");
             static bool attr_done = false;
             if (!attr_done) {

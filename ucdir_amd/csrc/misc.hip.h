@@ -231,11 +231,11 @@ __global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__
 // as the cropped fp32 NCHW result.  With 3 output channels the problem is HBM-bound (read x once, 170 MB at the
 // 288^2 level; 2.3 GFLOP): no activated copy of x is written and re-read, no 64-row matrix-core tile for 3 rows.
 // A workgroup (4 waves) owns a 16x16 pixel tile: the 18x18 halo is normalised + activated ONCE per element while
-// it is staged into LDS (bf16, rows padded by 16 B), then wave v takes pixel rows 4v..4v+3 as four 16-pixel
+// it is staged into LDS (bf16, 32 channels per pass, rows padded by 16 B), then wave v takes pixel rows 4v..4v+3 as four 16-pixel
 // column tiles of v_mfma_f32_16x16x32_bf16 (A = weights, rows >= cout zero; K step = one tap x 32 channels).
 // The weight fragments arrive pre-laid-out ([step][lane][8] bf16, pack_final_frags) and are copied to LDS once.
 // Pixels outside the image contribute 0 (the conv zero-pads the ACTIVATED tensor).
-// grid (ceil(W/16), ceil(H/16), B), block 256, dynamic LDS 324 * (2C + 16) + 9 * (C/32) * 1024 + 8C bytes; C % 32 == 0.
+// grid (ceil(W/16), ceil(H/16), B), block 256, dynamic LDS 324 * 80 + 9 * (C/32) * 1024 + 8C bytes; C % 32 == 0.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restrict__ x, int H, int W, int C,
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restric
                                                          float* __restrict__ out, int crop_h, int crop_w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int b = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
-    const int RS = 2 * C + 16;                         // LDS row (one halo pixel) in bytes
-    unsigned char* wl = fsm + 324 * RS;                // weight fragments
-    const int nstep = 9 * (C / 32);
+    constexpr int RS = 80;                             // LDS row: 32 channels of one halo pixel + 16 B pad
+    unsigned char* wl = fsm + 324 * RS;                // weight fragments, all steps
+    const int nc32 = C / 32, nstep = 9 * nc32;
     for (int it = threadIdx.x; it < nstep * 64; it += 256)
         *reinterpret_cast<uint4*>(wl + it * 16) = *reinterpret_cast<const uint4*>(wfrag + (long long)it * 8);
     float mean, rstd;
@@ -256,59 +256,56 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restric
         stat_read(stats, nullptr, b, S, Q);
         mean_rstd(S, Q, inv_count, mean, rstd);
     }
-    const int c8n = C / 8;
     const bf16_t* xb = x + (long long)b * (H + 2) * (W + 2) * C;
     float* gb = reinterpret_cast<float*>(wl + nstep * 1024);          // GN as one FMA: scale = rstd*gamma | shift = beta - mean*rstd*gamma
     for (int i = threadIdx.x; i < C; i += 256) { const float sc = rstd * gamma[i]; gb[i] = sc; gb[C + i] = beta[i] - mean * sc; }
-    const float inv_c8n = 1.0f / (float)c8n;
-    __syncthreads();
-    // halo staging in batches of 6 items per thread: all global loads of a batch are in flight before the first is used
-    for (int base = threadIdx.x; base < 324 * c8n; base += 256 * 6) {
-        uint4 v[6]; int dst[6];
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int it = base + u * 256;
-            v[u] = make_uint4(0, 0, 0, 0); dst[u] = -1;
-            if (it < 324 * c8n) {
-                const int hp = fdiv_small(it, inv_c8n), c = (it - hp * c8n) * 8;
-                const int hr = hp / 18, hc = hp - hr * 18;
-                const int gy = y0 + hr - 1, gx = x0 + hc - 1;      // image coordinates of this halo pixel
-                dst[u] = (hp * RS + c * 2) | ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0 : (1 << 30));
-                if (!(dst[u] >> 30)) v[u] = *reinterpret_cast<const uint4*>(xb + ((long long)(gy + 1) * (W + 2) + gx + 1) * C + c);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            if (dst[u] < 0) continue;
-            uint4 o = make_uint4(0, 0, 0, 0);
-            const int off = dst[u] & ((1 << 30) - 1);
-            if (!(dst[u] >> 30)) {
-                const int it = base + u * 256;
-                const int c = (it - fdiv_small(it, inv_c8n) * c8n) * 8;
-                const bf16_t* h = reinterpret_cast<const bf16_t*>(&v[u]);
-                float fv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) fv[k] = silu_fast(fmaf(bf2f(h[k]), gb[c + k], gb[C + c + k]));
-                o = pack8_bf16(fv);
-            }
-            *reinterpret_cast<uint4*>(fsm + off) = o;
-        }
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, kg = lane >> 4;
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    int step = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        for (int c32 = 0; c32 < C; c32 += 32, ++step) {
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl + (step * 64 + lane) * 16);
+    // 32 channels per pass keep the halo at 26 KB (three workgroups per CU instead of two at C = 64)
+    for (int c32 = 0; c32 < nc32; ++c32) {
+        __syncthreads();                               // gb ready (first pass) / previous pass done with the halo
+        // halo staging: 324 pixels x 4 sixteen-byte items = 1296 items, 6 per thread, all loads in flight before first use
+        {
+            uint4 v[6]; int dst[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int it = threadIdx.x + u * 256;
+                v[u] = make_uint4(0, 0, 0, 0); dst[u] = -1;
+                if (it < 324 * 4) {
+                    const int hp = it >> 2, c = (it & 3) * 8;
+                    const int hr = hp / 18, hc = hp - hr * 18;
+                    const int gy = y0 + hr - 1, gx = x0 + hc - 1;      // image coordinates of this halo pixel
+                    dst[u] = (hp * RS + c * 2) | ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0 : (1 << 30));
+                    if (!(dst[u] >> 30)) v[u] = *reinterpret_cast<const uint4*>(xb + ((long long)(gy + 1) * (W + 2) + gx + 1) * C + c32 * 32 + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                if (dst[u] < 0) continue;
+                uint4 o = make_uint4(0, 0, 0, 0);
+                const int off = dst[u] & ((1 << 30) - 1);
+                if (!(dst[u] >> 30)) {
+                    const int c = c32 * 32 + ((threadIdx.x + u * 256) & 3) * 8;
+                    const bf16_t* h = reinterpret_cast<const bf16_t*>(&v[u]);
+                    float fv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) fv[k] = silu_fast(fmaf(bf2f(h[k]), gb[c + k], gb[C + c + k]));
+                    o = pack8_bf16(fv);
+                }
+                *reinterpret_cast<uint4*>(fsm + off) = o;
+            }
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl + ((tap * nc32 + c32) * 64 + lane) * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int hp = (wv * 4 + t + ky) * 18 + col + kx;
-                const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(fsm + hp * RS + (c32 + kg * 8) * 2);
+                const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(fsm + hp * RS + kg * 16);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
             }
         }
