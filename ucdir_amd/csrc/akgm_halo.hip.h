@@ -48,6 +48,11 @@ __global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_coun
         Tc[((long long)b * 9 + cls) * n + o] = (bias[o] + Tb[(long long)cls * n + o]) * inv - mean * Tg[(long long)cls * n + o];
 }
 
+// ATT_LDS (16 / 32 channels per group: one halo chunk per workgroup, the second halo buffer is free): the per-pixel
+// modulation weights G*attw live in that buffer instead of 16 VGPRs, and the accumulators start at the fold constants
+// (as in akgm_pre.hip.h) so the epilogue needs 8 instead of 16 FMAs per output.  With 64 per group both halo buffers
+// are in use and the register version stays.
+template <bool ATT_LDS>
 __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     float* stage = reinterpret_cast<float*>(aring);                  // aliases the A ring between units
     float* scal = reinterpret_cast<float*>(smem + 2 * HC_HALO_BYTES + 2 * AH_ASTAGE);
     float* tcs = scal + 32;                                          // [9][128]
+    float* attl = reinterpret_cast<float*>(halo + HC_HALO_BYTES);    // ATT_LDS: [256 px][8]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: no waterfall loops around global_load_lds
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
 
     // ---- per-lane pixel constants --------------------------------------------------------------------
     int hp0[2], cls[2]; bool valid[2];
-    float att[2][8];
+    float att[ATT_LDS ? 1 : 2][8];
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
         int slot = wq * 64 + tp * 32 + (lane & 31);
@@ -130,8 +136,16 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         const float* gp = p.G + (long long)b * p.g_bstride + ((long long)y * p.W + x) * 8;
         const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
         const float* aw = p.attw + b * 8;
-        att[tp][0] = g0.x * aw[0]; att[tp][1] = g0.y * aw[1]; att[tp][2] = g0.z * aw[2]; att[tp][3] = g0.w * aw[3];
-        att[tp][4] = g1.x * aw[4]; att[tp][5] = g1.y * aw[5]; att[tp][6] = g1.z * aw[6]; att[tp][7] = g1.w * aw[7];
+        if (ATT_LDS) {
+            if (wm == 0) {                   // the two row halves see the same pixels: one of them publishes G * attw
+                float* ap = attl + (wq * 64 + tp * 32 + (lane & 31)) * 8;
+                *reinterpret_cast<float4*>(ap) = make_float4(g0.x * aw[0], g0.y * aw[1], g0.z * aw[2], g0.w * aw[3]);
+                *reinterpret_cast<float4*>(ap + 4) = make_float4(g1.x * aw[4], g1.y * aw[5], g1.z * aw[6], g1.w * aw[7]);
+            }
+        } else {
+            att[tp][0] = g0.x * aw[0]; att[tp][1] = g0.y * aw[1]; att[tp][2] = g0.z * aw[2]; att[tp][3] = g0.w * aw[3];
+            att[tp][4] = g1.x * aw[4]; att[tp][5] = g1.y * aw[5]; att[tp][6] = g1.z * aw[6]; att[tp][7] = g1.w * aw[7];
+        }
     }
     int a_off[2], a_sw[2];
 #pragma unroll
@@ -179,17 +193,36 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         AH_STAMP();
         issue_A(0, 0);
         f32x16_t acc[2][2];
+        if (!ATT_LDS) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
+                for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+        }
 
         int cch = 0, sp = 0;                     // halo chunk and stage index within the chunk period
         for (int s = 0; s < nk; ++s) {
             HC_WAIT(0);
             asm volatile("s_barrier" ::: "memory");
+            if (ATT_LDS && s == 0) {
+                // the fold table slice has landed: start at Tc[cls(pixel)][row] (registers 8q..8q+7 of a tile = the 8 sets
+                // of feature 4*t32 + 2q + hh, original row order 8*feature + set)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    const float* tc = tcs + cls[tp] * AH_TM;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float* t8 = tc + 8 * (4 * (wm * 2 + tm) + 2 * q + hh);
+                            const float4 c0 = *reinterpret_cast<const float4*>(t8), c1 = *reinterpret_cast<const float4*>(t8 + 4);
+                            acc[tm][tp][8 * q + 0] = c0.x; acc[tm][tp][8 * q + 1] = c0.y; acc[tm][tp][8 * q + 2] = c0.z; acc[tm][tp][8 * q + 3] = c0.w;
+                            acc[tm][tp][8 * q + 4] = c1.x; acc[tm][tp][8 * q + 5] = c1.y; acc[tm][tp][8 * q + 6] = c1.z; acc[tm][tp][8 * q + 7] = c1.w;
+                        }
+                }
+            }
             if (s + 1 < nk) issue_A(s + 1, (s + 1) & 1);
             const unsigned char* Hb = halo + cch * HC_HALO_BYTES;
             const unsigned char* Ab = aring + (s & 1) * AH_ASTAGE;
@@ -233,18 +266,30 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
         for (int tp = 0; tp < 2; ++tp) {
             const int px = wq * 64 + tp * 32 + (lane & 31);
             const float* tc = tcs + cls[tp] * AH_TM;
+            float av[8];
+            if (ATT_LDS) {
+                const float4 a0 = *reinterpret_cast<const float4*>(attl + px * 8), a1 = *reinterpret_cast<const float4*>(attl + px * 8 + 4);
+                av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) av[s] = att[ATT_LDS ? 0 : tp][s];
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const int t32 = wm * 2 + tm;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int floc = 4 * t32 + 2 * q + hh;
-                    const float4 c0 = *reinterpret_cast<const float4*>(tc + 8 * floc);
-                    const float4 c1 = *reinterpret_cast<const float4*>(tc + 8 * floc + 4);
-                    const float tcv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                     float sa = 0.f, sb = 0.f;
+                    if (!ATT_LDS) {
+                        const float4 c0 = *reinterpret_cast<const float4*>(tc + 8 * floc);
+                        const float4 c1 = *reinterpret_cast<const float4*>(tc + 8 * floc + 4);
+                        const float tcv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) { sa += att[tp][s] * acc[tm][tp][8 * q + s]; sb += att[tp][s] * tcv[s]; }
+                        for (int s = 0; s < 8; ++s) sb += av[s] * tcv[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) sa += av[s] * acc[tm][tp][8 * q + s];
                     stage[px * AH_SL + floc] = valid[tp] ? rstd * (sa + sb) : 0.f;
                 }
             }

@@ -338,7 +338,8 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
 static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
+        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
+        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
         HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<8>::LDS));
         HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<16>::LDS));
         attr_done = true;
@@ -369,10 +370,13 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.stats_out = y.stats;
     const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.dbg = nullptr;
+    static const bool use_attlds = !getenv("UCDIR_NO_ATTLDS");
+    const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
     auto launch = [&]() {
         if (pre && w.cg == 8) hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
         else if (pre) hipLaunchKernelGGL(akgm_pre_kernel<16>, dim3(nblk), dim3(HC_THREADS), AkPre<16>::LDS, st, p);
-        else hipLaunchKernelGGL(akgm_halo_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        else hipLaunchKernelGGL(akgm_halo_kernel<false>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
     };
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
