@@ -25,8 +25,8 @@ def bench_name(k):
     if m:
         tm, epi, mode = int(m.group(1)), int(m.group(2)), int(m.group(3))
         return f"cgemm<{tm},akgm>" if epi == 1 else f"cgemm<{tm},std,{MODE[mode]}>"
-    if k.startswith("akgm_halo_kernel"):
-        return "akgm_halo"
+    if "akgm_halo_kernel" in k:
+        return "akgm_halo"                          # <true> / <false> instantiations share one bench row
     if "akgm_pre_kernel" in k:
         return "akgm_pre"
     m = re.search(r"conv3x3_halo_kernel<(\d+)(?:, (true|false))?>", k)
@@ -59,6 +59,7 @@ def main():
     fe = agg(os.path.join(src, "pmc_fetch", [f for f in os.listdir(os.path.join(src, "pmc_fetch")) if f.endswith("counter_collection.csv")][0]), "FETCH_SIZE")
     wr = agg(os.path.join(src, "pmc_write", [f for f in os.listdir(os.path.join(src, "pmc_write")) if f.endswith("counter_collection.csv")][0]), "WRITE_SIZE")
     traffic = {}
+    tsum = {}
     with open(f"profiles/{tag}_pmc_hbm.csv", "w") as out:
         out.write("kernel,launches,FETCH_SIZE_KiB_per_launch,WRITE_SIZE_KiB_per_launch,hbm_bytes_per_launch_corrected\n")
         for k in sorted(fe, key=lambda k: -fe[k][1]):
@@ -68,8 +69,10 @@ def main():
             b = (2 * f_ + w_) * 1024
             out.write(f"\"{k[:90]}\",{n},{f_:.1f},{w_:.1f},{b:.0f}\n")
             bn = bench_name(k)
-            if bn:
-                traffic[bn] = b
+            if bn:                                      # several instantiations -> launch-weighted mean
+                tb, tn = tsum.get(bn, (0.0, 0))
+                tsum[bn] = (tb + b * n, tn + n)
+                traffic[bn] = tsum[bn][0] / tsum[bn][1]
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
