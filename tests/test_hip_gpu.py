@@ -195,3 +195,27 @@ def test_checkpoint_roundtrip(tmp_path):
         b = ddpm.netG.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda())
         pa, pb = net.predictor(cond.cuda()), ddpm.netG.predictor(cond.cuda())
     assert torch.equal(a, b) and torch.equal(pa, pb)
+
+
+@pytest.mark.gpu
+def test_alternative_kernel_paths_agree():
+    """The default dispatch (resident-weight AKGM, LDS-resident modulation weights, res_conv fused as a 10th tap,
+    fused final conv) and the plain kernels behind the UCDIR_NO_* switches compute the same forward: both are run
+    against the oracle in fresh processes (the switches are read once per process)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env_extra in (("default", {}), ("plain", {"UCDIR_NO_PRE": "1", "UCDIR_NO_ATTLDS": "1", "UCDIR_NO_FUSED_RES": "1",
+                                                       "UCDIR_NO_FUSED_FINAL": "1"})):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py"), "small"], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("[forward SMALL")][0]
+        assert "FAILED" not in line, line
+        out[tag] = json.loads(line[line.index("{"):])
+    for tag, m in out.items():
+        assert not m["eps"]["nan"] and m["eps"]["rel_rms"] < 2.5e-2, (tag, m["eps"])
+    assert abs(out["default"]["eps"]["rel_rms"] - out["plain"]["eps"]["rel_rms"]) < 5e-3, (out["default"]["eps"], out["plain"]["eps"])
