@@ -360,6 +360,61 @@ def ddim_sample(sd: SD, tab: dict, cond: torch.Tensor, guide: torch.Tensor, nois
     return img
 
 
+def dpm_solver_pp_sample(sd: SD, tab: dict, cond: torch.Tensor, guide: torch.Tensor, x_T: torch.Tensor, steps: int = 20,
+                         order: int = 2, eps_fn=None, **fw) -> torch.Tensor:
+    """The sampling the reference's ``dpm_solver()`` driver performs (sr.py:185-231, without the final ``+ initx``):
+    DPM-Solver++ multistep (Lu et al. 2022) on the discrete VP schedule of ``tab['betas']``, uniform time grid from
+    t = 1 to t = 1/N, data prediction x0 = (x - sigma eps) / alpha, network time input (t - 1/N) * 1000
+    (``model_wrapper``, sr.py:129-183).  The third-party solver package is not part of the reference tree: this is an
+    independent restatement of the published update rules (written in the exponential-integrator form
+    x_t = (sigma_t/sigma_s) x_s + alpha_t (1 - e^{-h}) [x0_s + (x0_s - x0_r) / (2 r)],  h = lambda_t - lambda_s,
+    r = (lambda_s - lambda_r) / h), parity unpinned against the package.  ``eps_fn(x, t)`` overrides the network
+    (host tests)."""
+    betas = np.asarray(tab["betas"], dtype=np.float64)
+    N = len(betas)
+    grid_t = np.arange(1, N + 1, dtype=np.float64) / N
+    grid_la = 0.5 * np.cumsum(np.log1p(-betas))
+
+    def log_alpha(t):
+        return float(np.interp(t, grid_t, grid_la)) if grid_t[0] <= t <= grid_t[-1] else \
+            float(grid_la[0] + (t - grid_t[0]) * (grid_la[1] - grid_la[0]) / (grid_t[1] - grid_t[0]))
+
+    def alpha(t):
+        return math.exp(log_alpha(t))
+
+    def sigma(t):
+        return math.sqrt(-math.expm1(2.0 * log_alpha(t)))
+
+    def lam(t):
+        return log_alpha(t) - math.log(sigma(t))
+
+    def x0_pred(x, t):
+        if eps_fn is not None:
+            eps = eps_fn(x, t)
+        else:
+            lvl = torch.full((cond.shape[0], 1), (t - 1.0 / N) * 1000.0, dtype=torch.float32)
+            eps = dy3h_forward(sd, torch.cat([cond, x], dim=1), lvl, guide, **fw)
+        return (x - sigma(t) * eps) / alpha(t)
+
+    ts = [1.0 + (1.0 / N - 1.0) * i / steps for i in range(steps + 1)]
+    x = x_T
+    hist = [(ts[0], x0_pred(x, ts[0]))]
+    for i in range(1, steps + 1):
+        s_t, s_x0 = hist[-1]
+        t = ts[i]
+        h = lam(t) - lam(s_t)
+        use2 = order == 2 and len(hist) == 2 and not (steps < 10 and i == steps)
+        d = s_x0
+        if use2:
+            r_t, r_x0 = hist[-2]
+            r = (lam(s_t) - lam(r_t)) / h
+            d = s_x0 + (s_x0 - r_x0) / (2.0 * r)
+        x = (sigma(t) / sigma(s_t)) * x + alpha(t) * (-math.expm1(-h)) * d
+        if i < steps:
+            hist = (hist + [(t, x0_pred(x, t))])[-2:]
+    return x
+
+
 def super_resolution(sd: SD, tab: dict, x_in: torch.Tensor, noises, continous: bool = False, **fw):
     """ResiGaussianGuideDY.super_resolution (diffusion.py:473-478)."""
     initx = predictor_forward(sd, x_in)

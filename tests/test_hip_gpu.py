@@ -168,6 +168,26 @@ def test_ddim_sample_matches_oracle():
     assert m["rel_rms"] < 3e-2, m
 
 
+def test_dpm_solver_sample_matches_oracle():
+    """DPM-Solver++ multistep sampler (the reference's sr.py:185-231 driver, 20 UNet calls instead of 50) through the
+    same denoiser boundary: HIP path vs the oracle's independent restatement with the CPU denoiser."""
+    from oracle import ucdir_oracle as O
+    from ucdir_amd.weights import synth_inputs
+    net, sd = C.build_net(SMALL)
+    sched = dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=0.4)
+    tab = O.schedule_tables(sched)
+    net.set_new_noise_schedule(sched, torch.device("cuda"))
+    cond, guide, _ = map(torch.from_numpy, synth_inputs(1, 64, 64, seed=11))
+    x_T = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    ref = O.dpm_solver_pp_sample(sd, tab, cond, guide, x_T, steps=6, order=2)
+    net.noise_source = lambda shape, device, k: x_T.to(device)
+    with torch.no_grad():
+        got = net.dpm_solver_sample(cond.cuda(), steps=6, order=2, kwargs={"guide": guide.cuda()})
+    net.noise_source = None
+    m = C.metrics(got, ref)
+    assert not m["nan"] and m["rel_rms"] < 3e-2, m
+
+
 def test_checkpoint_roundtrip(tmp_path):
     """Reference-style EMA checkpoint (`{prefix}_gen_ema.pth`, training-length schedule buffers included,
     model/model.py:193-251) loads through DDPM.load_network and reproduces the forward."""

@@ -177,6 +177,24 @@ class GaussianDiffusion(nn.Module):
         return img if not continous else torch.stack(imgs, dim=1)
 
     @torch.no_grad()
+    def dpm_solver_sample(self, x_in, steps=20, order=2, kwargs={}):
+        """The sampler of the reference's ``dpm_solver()`` driver (sr.py:185-231): DPM-Solver++ multistep on the discrete
+        schedule ``self.betas``, the network conditioned on ``x_in`` (channel concat) and on ``guide``; the caller adds
+        ``initx``.  ``steps`` UNet forwards instead of ``num_timesteps``."""
+        from . import dpm_solver as D
+        ns = D.NoiseScheduleVP(self.betas)
+        guide = kwargs.get("guide")
+        B = x_in.shape[0]
+
+        def model_eps(x, t):
+            lvl = torch.full((B, 1), ns.model_input_time(t), dtype=torch.float32, device=x_in.device)
+            if self._small(x):
+                return self.denoise_fn.forward_split(x_in, x, lvl, guide)
+            return self.denoise_fn(torch.cat([x_in, x], dim=1), lvl, guide)
+
+        return D.sample(model_eps, ns, self._noise(x_in, 0), steps=steps, order=order)
+
+    @torch.no_grad()
     def sample(self, batch_size=1, continous=False):
         raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
 
