@@ -61,7 +61,7 @@ struct DevPool {
         return p;
     }
     // statistics accumulators of every activation in this pool: one slab, zeroed with one memset per forward
-    static constexpr size_t STAT_CAP = 1 << 19;      // 4 MB: 128 activations x B = 64 x 16 slots x 2
+    static constexpr size_t STAT_CAP = 1 << 21;      // 16 MB: ~130 activations x B up to 500 x 16 slots x 2
     stat_t* stat_slab = nullptr; size_t stat_used = 0;
     stat_t* alloc_stats(int B) {
         if (!stat_slab) stat_slab = (stat_t*)alloc(STAT_CAP * sizeof(stat_t), true);
