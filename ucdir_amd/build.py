@@ -37,7 +37,11 @@ def needs_build():
 def build(force=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    # -fno-slp-vectorize: hipcc 7.2's SLP pass packs the fp32 statistics adds of cgemm_kernel<64> into v_pk_add_f32 /
+    # v_pk_fma_f32 with op_sel, and that code sums a few lanes wrongly and differently from run to run at the 288^2
+    # level (found by tests/test_hip_gpu.py::test_forward_bit_reproducible_at_bench_size; per-workgroup sums dumped:
+    # sum of squares bit-identical, plain sum off by 0.3 %).  Packed f32 VALU is no faster on gfx950 anyway.
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
            *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
