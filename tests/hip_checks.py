@@ -192,6 +192,31 @@ def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=N
     return out, eps.cpu(), ref
 
 
+def conv_stats_case(B, H, W, cin, cout, ksize, mode, gn, runs=3, seed=0):
+    """GroupNorm statistics a conv launch accumulates for its OUTPUT (fixed-point atomics) against float64 sums of the
+    output it stored, and their run-to-run reproducibility.  A size-independent property: usable at bench size."""
+    L = ulib.load()
+    g = rng(seed)
+    x = bfr(torch.randn(B, cin, H, W, generator=g) * 1.3 + 0.6).to(DEV)
+    w = (torch.randn(cout, cin, ksize, ksize, generator=g) * math.sqrt(1.5 / (cin * ksize * ksize))).numpy().copy()
+    b = (torch.randn(cout, generator=g) * 0.1).numpy().copy()
+    gm = (1 + 0.25 * torch.randn(cin, generator=g)).numpy().copy() if gn else None
+    bt = (0.2 * torch.randn(cin, generator=g)).numpy().copy() if gn else None
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode == 2 else (H, W))
+    outs, sts = [], []
+    for _ in range(runs):
+        y = torch.empty(B, cout, Ho, Wo, device=DEV)
+        st = np.zeros((B, 2), dtype=np.float64)
+        ulib.check(L.ucdir_op_conv(_p(x), cin, _p(None), 0, B, H, W, _hp(w), _hp(b), _hp(gm), _hp(bt), cout, ksize, mode, 1,
+                                   _p(None), _p(y), _hp(st), _st()))
+        torch.cuda.synchronize()
+        outs.append(y); sts.append(st.copy())
+    ref = np.stack([outs[0].double().sum(dim=(1, 2, 3)).cpu().numpy(), outs[0].double().pow(2).sum(dim=(1, 2, 3)).cpu().numpy()], 1)
+    return {"stats_rel": float(np.abs((sts[0] - ref) / ref).max()),
+            "outputs_reproducible": all(torch.equal(outs[0], o) for o in outs[1:]),
+            "stats_reproducible": all(np.array_equal(sts[0], s_) for s_ in sts[1:])}
+
+
 def predictor_case(B, H, W, seed=3, net_sd=None):
     """UNetSeeInDark on the HIP engine vs the oracle (model/ucdir.py:352-403)."""
     net, sd = net_sd if net_sd is not None else build_net(UNetConfig(inner_channel=64, channel_mults=(1, 2), res_blocks=1,

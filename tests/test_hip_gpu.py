@@ -116,6 +116,21 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
     assert float((a[0] - a[1]).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("args", [
+    (2, 288, 288, 128, 64, 1, 0, 0),      # cgemm<64> 1x1 at the 288^2 level (the launch hipcc's packed-f32 code got wrong)
+    (4, 288, 288, 64, 64, 3, 1, 0),       # cgemm<64> stride-2 Downsample
+    (2, 288, 288, 64, 64, 3, 0, 1),       # conv3x3_halo<64> with the GroupNorm fold
+    (2, 144, 144, 128, 128, 3, 0, 1),     # conv3x3_halo<128>
+    (2, 72, 72, 256, 256, 3, 2, 0),       # Upsample parity launches
+], ids=["1x1_64", "down_64", "halo_64", "halo_128", "up_256"])
+def test_output_statistics_exact_and_reproducible(args):
+    """The (sum, sum of squares) a launch accumulates with fixed-point atomics equal float64 sums of the output it stored
+    (up to the bf16 rounding of that output) and are bit-identical from run to run, at the network's real level sizes."""
+    m = C.conv_stats_case(*args)
+    assert m["outputs_reproducible"] and m["stats_reproducible"], m
+    assert m["stats_rel"] < 3e-5, m
+
+
 def test_sampler_8_steps_psnr(sid_net):
     m = C.sampler_case(SID, 64, 64, 8, net_sd=sid_net)
     assert m["psnr_u8"] > 35.0, m               # bf16 bound from SURVEY.md §8c
