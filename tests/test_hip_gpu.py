@@ -114,6 +114,14 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
     assert torch.equal(a, b)
     assert bool(torch.isfinite(a).all()) and a.shape == (16, 3, 256, 256)
     assert float((a[0] - a[1]).abs().max()) > 1e-3
+    # sample 5 launched alone: small grids switch some layers to 64-row tiles (engine.hip run_conv), i.e. another fp32
+    # summation order -> another realisation of the bf16 rounding noise, which this random-weight network amplifies
+    # to the size of the build-vs-oracle error itself (measured 1.1e-2); bit-exactness holds when the tilings agree
+    # (test_forward_batch_is_independent)
+    with torch.no_grad():
+        one = net.denoise_fn(x6[5:6].contiguous(), lvl[5:6].cuda(), guide[5:6].cuda())
+    m = C.metrics(a[5:6], one.cpu())
+    assert m["rel_rms"] < FWD_TOL, m
 
 
 @pytest.mark.parametrize("args", [
