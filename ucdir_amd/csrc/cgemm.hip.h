@@ -26,14 +26,11 @@
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// one LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at a wave-uniform base
+// (written lane-linearly: any swizzle goes on the SOURCE address)
 __device__ __forceinline__ void stage16(const bf16_t* gsrc, unsigned char* lds_wave_base, int lane) {
-#ifdef UCDIR_REGSTAGE
-    uint4 v = *reinterpret_cast<const uint4*>(gsrc);
-    *reinterpret_cast<uint4*>(lds_wave_base + lane * 16) = v;
-#else
     (void)lane;
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
-#endif
 }
 
 __device__ __forceinline__ int tap_ky(int tap) { return (tap * 11) >> 5; }   // tap / 3 for 0..8
@@ -213,9 +210,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         issue(0, 0);
         for (int ks = 0; ks < p.nk; ++ks) {
             const int buf = ks & 1;
-#ifndef UCDIR_REGSTAGE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __syncthreads();
             if (ks + 1 < p.nk) issue(ks + 1, buf ^ 1);
             const unsigned char* Ab = smem + buf * (TM * 128);
