@@ -139,6 +139,25 @@ def test_output_statistics_exact_and_reproducible(args):
     assert m["stats_rel"] < 3e-5, m
 
 
+def test_restoration_is_bit_reproducible(sid_net):
+    """super_resolution (predictor + 4 sampler steps with injected noise) twice on the same inputs: identical bits."""
+    net, sd = sid_net
+    from ucdir_amd.weights import synth_inputs
+    dev = torch.device("cuda")
+    net.set_new_noise_schedule(dict(schedule="linear", n_timestep=4, linear_start=1e-6, linear_end=0.4), dev)
+    cond = torch.from_numpy(synth_inputs(2, 256, 256, seed=8)[0]).to(dev)
+    g = torch.Generator().manual_seed(2)
+    noises = [torch.randn(2, 3, 256, 256, generator=g) for _ in range(5)]
+    net.noise_source = lambda shape, device, k: noises[k].to(device)
+    try:
+        with torch.no_grad():
+            a = net.super_resolution(cond, False).clone()
+            b = net.super_resolution(cond, False)
+    finally:
+        net.noise_source = None
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
 def test_sampler_8_steps_psnr(sid_net):
     m = C.sampler_case(SID, 64, 64, 8, net_sd=sid_net)
     assert m["psnr_u8"] > 35.0, m               # bf16 bound from SURVEY.md §8c
