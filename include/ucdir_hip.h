@@ -22,7 +22,10 @@
  *   - all work is enqueued on the hipStream_t passed in (as void*) and is asynchronous;
  *   - a handle is not thread-safe (one handle per device / per process, like the reference's
  *     one-process-per-GPU use); the library owns packed weights + workspace, the caller owns
- *     every tensor it passes in.
+ *     every tensor it passes in;
+ *   - every entry point that takes a handle runs on the handle's device and restores the calling
+ *     thread's current HIP device before it returns; ucdir_sampler_step runs on the device that
+ *     owns x_t; the single-operator test entry points (ucdir_op_*) use the current device.
  */
 #ifndef UCDIR_HIP_H
 #define UCDIR_HIP_H
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define UCDIR_ABI_VERSION 1
+#define UCDIR_ABI_VERSION 2
 #define UCDIR_MAX_MULTS 8
 
 typedef struct ucdir_ctx ucdir_ctx;
@@ -51,6 +54,9 @@ typedef struct ucdir_config {
     int32_t res_blocks;                     /* 2                                     */
     int32_t image_size;                     /* 128 (only used to place attention)    */
     int32_t device;                         /* HIP device ordinal                    */
+    int32_t attn_fp16;                      /* 0: bf16 attention operands (default); 1: IEEE-half q, k, v', P on
+                                             * v_mfma_*_f16 (the JPEG configuration's "fp16 attention MFMA path",
+                                             * BASELINE.json configs[4]); accumulation, softmax and output stay fp32/bf16 */
 } ucdir_config;
 
 int32_t     ucdir_abi_version(void);
@@ -83,9 +89,16 @@ int32_t ucdir_prepare_guide(ucdir_ctx* ctx, const float* guide, int32_t B, int32
 
 /* ---- the denoiser: eps = DY3h(cat[cond, x_t], noise_level, guide) ----------------------
  * cond, x_t: (B,3,H,W) fp32 (the channel concat of model/diffusion.py:166 is done on the fly);
- * noise_level: (B) fp32; eps: (B,3,H,W) fp32.  Shapes must match the last prepare_guide. */
+ * noise_level: (B) fp32; eps: (B,3,H,W) fp32.  (B,H,W) must equal the shape of the last
+ * ucdir_prepare_guide: a mismatch is an error, never an out-of-bounds access. */
 int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t,
-                           const float* noise_level, float* eps, void* stream);
+                           const float* noise_level, float* eps,
+                           int32_t B, int32_t H, int32_t W, void* stream);
+/* B = 1 / `-p val` latency path: with on != 0 every ucdir_unet_forward is replayed from a HIP graph
+ * captured once per (cond, x_t, noise_level, eps) pointer set (keep them in persistent buffers, as
+ * ucdir_amd.diffusion.p_sample_loop does); ~150 launches become one hipGraphLaunch.  Graphs are
+ * dropped when weights are re-finalised or the planned shape changes. */
+int32_t ucdir_set_graph(ucdir_ctx* ctx, int32_t on);
 
 /* ---- ancestral sampler update (model/diffusion.py:150-158,171-183), in place on x_t:
  *   x0   = clamp(c_recip * x_t - c_recipm1 * eps, -1, 1)
@@ -102,6 +115,10 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
 int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst,
                          int64_t dst_elems, void* stream);
 int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
+/* Process-wide test switches, read when a shape is planned / an op entry point runs.
+ * "flash": 1 = flash-attention kernel, 0 = materialised-score path (QK^T, softmax, PV as three launches),
+ * -1 = environment default (UCDIR_NO_FLASH).  Unknown names are an error. */
+int32_t ucdir_debug_flag(const char* name, int32_t value);
 /* Per-launch HIP-event timing of the GEMM-core kernels (bench.py's roofline leg).  While enabled,
  * every launch is bracketed by events on its stream; ucdir_profile_read synchronises the stream and
  * aggregates per kernel instantiation: key = 100*[TM==128] + 10*[AKGM epilogue] + column mode
@@ -145,7 +162,7 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res,
 int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int32_t W,
                            const float* gamma_host, const float* beta_host,
                            const float* wqkv_host, const float* wout_host, const float* bout_host,
-                           float* y, void* stream);
+                           int32_t fp16, float* y, void* stream);
 
 #ifdef __cplusplus
 }

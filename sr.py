@@ -4,9 +4,13 @@
 Counterpart of the reference's ``sr.py`` val branch (sr.py:320-400, 505-586): same flags, same YAML
 schema, same per-image outputs ``{results}/{fname}_{name}_{sr,hr,lr,inf}.jpg`` and the
 ``# Validation # PSNR/SSIM`` log lines.  One process per GPU; with N ranks
-(``python -m torch.distributed.run --nproc-per-node N sr.py ...``) images are strided over ranks
-like the reference's EnlargedSampler (data/data_sampler.py:44-45) and no collective is issued
-except the final metric reduction.  Training (``-p train``) is out of scope for this build.
+(``python -m torch.distributed.run --nproc-per-node N sr.py ...``):
+  * images small enough for one denoiser call are strided over ranks like the reference's EnlargedSampler
+    (data/data_sampler.py:44-45), no data-path collective;
+  * images that take the inter-step patch split (padded area > 1024^2, model/ucdir.py:298) are restored by ALL ranks
+    together: the windows of every step are sharded over the ranks with one RCCL all-gather per step
+    (ucdir_amd/patch.py), every rank draws the same noise; rank 0 writes the outputs.
+Training (``-p train``) is out of scope for this build.
 
 Without a checkpoint (none ships with the reference) ``--synthetic-weights`` fills the network with
 the deterministic generator used by the tests, so the plumbing can be exercised end to end.
@@ -70,7 +74,7 @@ def main(argv=None):
     if args.synthetic_weights:
         from ucdir_amd.weights import synth_state_dict
         sd = synth_state_dict(diffusion.netG.denoise_fn.cfg, 0)
-        diffusion.netG.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        Model.load_checkpoint_state(diffusion.netG, {k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     diffusion.set_new_noise_schedule(opt["model"]["beta_schedule"]["val"], schedule_phase="val")
 
     logger.info("Begin Model Evaluation. len %d" % len(val_set))
@@ -78,21 +82,29 @@ def main(argv=None):
     os.makedirs(result_path, exist_ok=True)
     tot_psnr = tot_ssim = 0.0
     n = 0
-    idxs = list(range(rank, len(val_set), world))
+    idxs = list(range(len(val_set)))
     if args.max_images > 0:
-        idxs = idxs[:args.max_images]
+        idxs = idxs[:args.max_images * world]
+    thr = diffusion.netG.denoise_fn.patch_threshold
+    nsmall = 0
     for i in idxs:
         item = val_set[i]
+        h, w = item["SR"].shape[-2:]
+        shared = world > 1 and (h + 128) * (w + 128) > thr        # DDPM.test pads 64 per side: this image is patch-split
+        if not shared:
+            mine = (nsmall % world) == rank
+            nsmall += 1
+            if not mine:
+                continue
         fname = os.path.splitext(os.path.basename(val_set.sr_path[i]))[0]
         data = {k: (v.unsqueeze(0) if torch.is_tensor(v) else v) for k, v in item.items()}
         with torch.no_grad():
             diffusion.feed_data(data)
             diffusion.test(continous=True)
-        vis = diffusion.get_current_visuals()
-        hr_img = Metrics.tensor2img(vis["HR"])
-        lr_img = Metrics.tensor2img(vis["LR"])
-        fake_img = Metrics.tensor2img(diffusion.netG.pre_initx.detach().float().cpu()[..., 64:-64, 64:-64])
-        sr_img = Metrics.tensor2img(vis["SR"][-1])
+        if shared and rank != 0:
+            continue                                              # every rank holds the same result; rank 0 reports it
+        vis = diffusion.visuals_u8()
+        hr_img, lr_img, fake_img, sr_img = vis["HR"], vis["LR"], vis["INF"], vis["SR"]
         name = opt["name"]
         Metrics.save_jpg(sr_img, "{}/{}_{}_sr.png".format(result_path, fname, name))
         Metrics.save_jpg(hr_img, "{}/{}_{}_hr.png".format(result_path, fname, name))

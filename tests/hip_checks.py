@@ -121,7 +121,7 @@ def akgm_case(B, C, H, W, seed=0):
     return m
 
 
-def attention_case(B, C, H, W, seed=0):
+def attention_case(B, C, H, W, seed=0, fp16=False):
     L = ulib.load()
     g = rng(seed)
     x = bfr(torch.randn(B, C, H, W, generator=g) * 1.2 + 0.3)
@@ -134,7 +134,8 @@ def attention_case(B, C, H, W, seed=0):
     n = lambda k: sd[k].numpy().copy()
     dx = x.to(DEV)
     ulib.check(L.ucdir_op_attention(_p(dx), B, C, H, W, _hp(n("a.norm.weight")), _hp(n("a.norm.bias")),
-                                    _hp(n("a.qkv.weight")), _hp(n("a.out.weight")), _hp(n("a.out.bias")), _p(dy), _st()))
+                                    _hp(n("a.qkv.weight")), _hp(n("a.out.weight")), _hp(n("a.out.bias")), int(fp16),
+                                    _p(dy), _st()))
     torch.cuda.synchronize()
     # the residual dominates y; report the error relative to the attention branch alone
     m = metrics(dy, y)

@@ -20,7 +20,7 @@ SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, 
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = lib.load()
-    assert L.ucdir_abi_version() == 1
+    assert L.ucdir_abi_version() == 2
     hdr = open(os.path.join(ROOT, "include", "ucdir_hip.h")).read()
     declared = set(re.findall(r"\b(ucdir_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ucdir_ctx", "ucdir_config"}
@@ -149,3 +149,156 @@ def test_metrics_restatement():
     assert M.calculate_psnr(a, a) == float("inf") and abs(M.calculate_ssim(a, a) - 1.0) < 1e-12
     b = a.copy(); b[0, 0, 0] ^= 8
     assert abs(M.calculate_psnr(a, b) - O.psnr(a, b)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: sharded patch split wired into the product entry points, rank-identical noise, checkpoint strictness
+# ------------------------------------------------------------------------------------------------------------------
+def _dy3h_stub(group=None):
+    """A product DY3h whose engine call (naiveforward) is replaced by the CPU toy denoiser: DY3h.forward's own dispatch
+    (threshold, skip / padding constants, patch_group) is what runs."""
+    from ucdir_amd.ucdir import DY3h
+    net = DY3h(inner_channel=64, channel_mults=(1, 2), res_blocks=1, attn_res=(64,))
+    net.naiveforward = _toy_net
+    net.patch_threshold, net.patch_skip, net.patch_padding = 100 * 100, 96, 16
+    net.patch_group, net.patch_max_batch = group, 2
+    return net
+
+
+def _dy3h_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ucdir_amd import model as M
+    net = _dy3h_stub()
+    # DDPM.setup_distributed is what sr.py / create_model run: it must hand the world group to the denoiser and seed the noise
+    holder = M.DDPM.__new__(M.DDPM)
+    holder.netG = type("G", (), {})()
+    holder.netG.denoise_fn = net
+    holder.setup_distributed()
+    assert net.patch_group is dist.group.WORLD and holder.netG.noise_seed is not None
+    torch.manual_seed(0)
+    x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
+    q.put((rank, net(x, t, g)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dy3h_forward_shards_windows_over_ranks_gloo():
+    """model/ucdir.py:298-300 through the PRODUCT dispatch: DY3h.forward on 2 gloo ranks (group set by
+    DDPM.setup_distributed) equals the reference's sequential window loop on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dy3h_worker, args=(r, 2, 29655, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    torch.manual_seed(0)
+    x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
+    ref = O.patch_forward_guide(x, _toy_net, t, g, skip=96, padding=16)
+    single = _dy3h_stub()(x, t, g)
+    assert torch.allclose(single, ref, atol=1e-6)
+    for r in range(2):
+        assert torch.allclose(outs[r], ref, atol=1e-6), r
+
+
+def test_patch_geometry_of_the_full_resolution_config():
+    """BASELINE configs[2]: 1424x2128 -> DDPM.test +128 -> patch pad +128 -> 1680x2384 -> six 1024^2 windows
+    (SURVEY.md §8 a10), two per rank on 3 GPUs, one on 6, at most one on 8."""
+    H, W = 1424 + 128, 2128 + 128
+    pd = patch.patch_pad(H, W, 1024, 64)
+    assert pd == 64
+    wins = patch.patch_windows(H + 2 * pd, W + 2 * pd, 1024, 64)
+    assert wins == [(0, 1024, 0, 1024), (0, 1024, 896, 1920), (0, 1024, 1360, 2384),
+                    (656, 1680, 0, 1024), (656, 1680, 896, 1920), (656, 1680, 1360, 2384)]
+    # GoPro 720x1280: min < skip -> pd = 1024 - 720 + 64 (utils/util.py:114-115)
+    assert patch.patch_pad(720, 1280, 1024, 64) == 368
+
+
+def test_constant_batch_chunks():
+    """Windows are cut into equal chunks (last one padded): the engine sees one batch size per step."""
+    seen = []
+
+    def net(x, time, guide):
+        seen.append(x.shape[0])
+        return _toy_net(x, time, guide)
+    torch.manual_seed(1)
+    x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
+    ref = O.patch_forward_guide(x, _toy_net, t, g, skip=96, padding=16)       # 12 windows
+    got = patch.patch_forward_guide(x, net, {"time": t, "guide": g}, skip=96, padding=16, max_batch=5)
+    assert torch.allclose(got, ref, atol=1e-6)
+    assert len(set(seen)) == 1 and seen[0] <= 5, seen
+
+
+def test_seeded_noise_is_identical_across_instances():
+    from ucdir_amd.diffusion import GaussianDiffusion
+    a, b = GaussianDiffusion(torch.nn.Identity(), 128), GaussianDiffusion(torch.nn.Identity(), 128)
+    like = torch.zeros(1, 3, 8, 8)
+    draws = []
+    for gd in (a, b):
+        gd.noise_seed = 77
+        gd._start_noise(torch.device("cpu"))
+        draws.append([gd._noise(like, k) for k in range(3)])
+    for u, v in zip(*draws):
+        assert torch.equal(u, v)
+    assert not torch.equal(draws[0][0], draws[0][1])
+    a._start_noise(torch.device("cpu"))                      # re-seeded at the start of every loop
+    assert torch.equal(a._noise(like, 0), draws[0][0])
+
+
+def test_config_overrides_gopro_and_jpeg(tmp_path):
+    import yaml
+    base = yaml.safe_load(open(os.path.join(ROOT, "config", "sid.yaml")))
+    for name, suffix, has_factor in (("gop-x", "full", False), ("jpg-q10", "fullimage10", True), ("other", "", False)):
+        cfg = dict(base); cfg["name"] = name
+        p = tmp_path / f"{name}.yaml"
+        yaml.safe_dump(cfg, open(p, "w"))
+        a = argparse.Namespace(config=str(p), phase="val", debug=False, checkpoint=None, enable_wandb=False)
+        o = config.parse(a, make_dirs=False)
+        T = o["model"]["beta_schedule"]["val"]["n_timestep"]
+        assert o["path"]["experiments_root"].endswith(f"_s{T}{suffix}"), o["path"]["experiments_root"]
+        da = o["datasets"]["val"]["data_args"]
+        if name != "other":
+            assert T == 50 and o["model"]["beta_schedule"]["val"]["linear_end"] == 0.4
+        assert (da["factor"] == [10, 10] and da["crop_size"] == -1) if has_factor else True
+        if name == "gop-x":
+            assert da["dataroot"]["lq"].endswith("GoPro/input/")
+
+
+def test_checkpoint_loading_is_strict_about_network_keys():
+    from ucdir_amd import model as M
+    from ucdir_amd import networks
+    opt = {"model": {"which_model_G": "ucdir", "unet_name": "DY3h", "diffusion_name": "ResiGaussianGuideDY",
+                     "unet": dict(in_channel=6, out_channel=3, inner_channel=64, channel_mults=[1, 2], attn_res=[64],
+                                  res_blocks=1, dropout=0, norm_groups=1),
+                     "diffusion": dict(image_size=128, channels=3, conditional=True)}}
+    net = networks.define_G(opt)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["betas"] = torch.zeros(2000)                                     # training-length buffer: skipped, not an error
+    rep = M.load_checkpoint_state(net, {"module." + k: v for k, v in sd.items()})     # DDP prefix stripped
+    assert rep["loaded"] == len(sd) - 1 and rep["skipped_buffers"] == ["betas"]
+    k0 = next(k for k in sd if k.startswith("denoise_fn.") and k.endswith("conv1.weight"))
+    with pytest.raises(RuntimeError, match="missing"):
+        M.load_checkpoint_state(net, {k: v for k, v in sd.items() if k != k0})
+    renamed = dict(sd); renamed["denoise_fn.renamed.weight"] = renamed.pop(k0)
+    with pytest.raises(RuntimeError):
+        M.load_checkpoint_state(net, renamed)
+    bad = dict(sd); bad[k0] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError, match="wrong shape"):
+        M.load_checkpoint_state(net, bad)
+    extra = dict(sd); extra["optimizer_step"] = torch.zeros(1)
+    M.load_checkpoint_state(net, extra)                                  # EMA path: unrelated keys are logged and ignored
+    with pytest.raises(RuntimeError):
+        M.load_checkpoint_state(net, extra, strict=True)                 # non-EMA path (strict = not finetune_norm)
+    assert net.denoise_fn._wdirty                                        # a load marks the engine's packed weights stale
+
+
+def test_device_side_uint8_conversion_matches_tensor2img():
+    from ucdir_amd import metrics as M
+    t = torch.randn(3, 17, 23, generator=torch.Generator().manual_seed(0)) * 0.8
+    t[0, 0, 0], t[1, 0, 0], t[2, 0, 0] = -1.0 + 1 / 255, 0.0, 1.0 - 1 / 255      # exact .5 cases round half to even
+    np.testing.assert_array_equal(M.tensor2img_u8_device(t), M.tensor2img(t))
+    np.testing.assert_array_equal(M.tensor2img_u8_device(t.unsqueeze(0)), O.tensor2img(t))

@@ -1,11 +1,16 @@
 """Config parsing for ``sr.py`` (reference: core/logger.py:22-199, re-done on PyYAML).
 
 Keeps the YAML schema of config/sid.yaml and the name-keyed validation overrides the reference
-hard-codes: phase ``val`` prefixes the name with ``val_``, names containing ``sid`` sample with
-T = 50, linear_end = 0.4 (core/logger.py:58-61); GoPro / JPEG names keep their own tables
-(core/logger.py:63-136); ``-ema`` is appended when the EMA scheduler is on (:141-142); the
-experiment directory is ``experiments/{timestamp}_{name}_s{T}`` (:144-154).
+hard-codes (core/logger.py:40-154): phase ``val`` prefixes the name with ``val_``; names containing
+``sid`` sample with T = 50, linear_end = 0.4 (:58-61); names containing ``gop-`` get the GoPro test
+roots, T = 50 / 0.4 and the directory suffix ``full`` (:63-112); names containing ``jpg-`` get the
+ImageNet-val root + list, ``factor = [10, 10]``, ``crop_size = -1``, T = 50 / 0.4 and the suffix
+``fullimage10`` (:113-136); any other name keeps the YAML schedule (the reference's ``assert 'val name
+not support'`` is a no-op string assert; here it is a logged warning); ``-ema`` is appended when the EMA
+scheduler is on (:141-142); the experiment directory is ``experiments/{timestamp}_{name}_s{T}{suffix}``
+(:144-149).
 """
+import logging
 import os
 from datetime import datetime
 
@@ -52,9 +57,22 @@ def parse(args, world_size=1, make_dirs=True):
         if "sid" in name:
             sched["n_timestep"], sched["linear_end"] = 50, 4e-1
         elif "gop-" in name:
+            da["dataroot"] = {"lq": "../Restormer/Motion_Deblurring/Datasets/test/GoPro/input/",
+                              "gt": "../Restormer/Motion_Deblurring/Datasets/test/GoPro/target/"}
+            fix += "full"
             sched["n_timestep"], sched["linear_end"] = 50, 4e-1
-        elif "jpeg" in name or "img" in name:
+        elif "jpg-" in name:
+            root = "../data/"
+            if not os.path.exists(root + "images"):
+                root = "../../data/"
+            da["dataroot"] = {"root": root + "images/val", "txt": "./imagenet_val_1k.txt"}
+            da["factor"] = [10, 10]
+            fix += "fullimage10"
+            da["crop_size"] = -1
             sched["n_timestep"], sched["linear_end"] = 50, 4e-1
+        else:
+            logging.getLogger("base").warning("val name %r has no sampling override (core/logger.py:138): the YAML "
+                                              "beta_schedule.val is used as written", name)
         if opt.get("train", {}).get("ema_scheduler", {}).get("use"):
             opt["name"] += "-ema"
     root = os.path.join("experiments", "{}_{}".format(get_timestamp(), opt["name"]))

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
             bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + opos * p.out_ld + p.out_coff + f;
-            *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
+            *reinterpret_cast<uint4*>(op) = p.out_f16 ? pack8_f16(v) : pack8_bf16(v);
         }
     }
     if (p.stats_out) {

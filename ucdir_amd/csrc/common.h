@@ -30,6 +30,15 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ uint4 pack8_bf16(const float* v) {
     return make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
 }
+// two fp32 -> packed IEEE half x2 (round-to-nearest-even)
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    h2_t v; v[0] = (_Float16)lo; v[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint4 pack8_f16(const float* v) {
+    return make_uint4(pack2_f16(v[0], v[1]), pack2_f16(v[2], v[3]), pack2_f16(v[4], v[5]), pack2_f16(v[6], v[7]));
+}
 
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // x / d for small non-negative ints (x < 2^15, d <= 1024) with inv = 1.0f / d: the +0.5 keeps the product at least
@@ -131,6 +140,7 @@ struct GemmP {
     const float* bias; const float* Tb; const float* Tg; int tab_ld;  // tables [ncls][tab_ld]
     const bf16_t* res; long long res_bstride; int res_ld; int res_coff;
     void* out; long long out_bstride; int out_ld; int out_coff; int out_f32; int out_compact;
+    int out_f16;                        // bf16-path stores write IEEE half instead (fp16-operand attention, qkv only)
     int out_nchw; int crop_h, crop_w;   // final conv: fp32 NCHW (B, nfeat, crop_h, crop_w)
     int shuffle_c;                      // > 0: ConvTranspose2d(2,2): feature f = q*shuffle_c + o goes to pixel (2y+q/2, 2x+q%2), channel o
     int nfeat;               // valid output features (rows) in total

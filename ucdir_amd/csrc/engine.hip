@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <array>
 #include <memory>
 #include <string>
@@ -16,6 +17,7 @@
 #include "conv_halo.hip.h"
 #include "akgm_halo.hip.h"
 #include "akgm_pre.hip.h"
+#include "flash_attn.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -40,6 +42,17 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     return 0;
 
 static void require(bool c, const std::string& m) { if (!c) throw std::runtime_error(m); }
+
+// Every API entry that touches a context runs on the context's device and leaves the caller's current device as it
+// found it (PyTorch tracks its own notion of the current device).  Handles are not thread-safe (include/ucdir_hip.h).
+struct DevGuard {
+    int prev = -1; bool changed = false;
+    explicit DevGuard(int dev) {
+        HIPC(hipGetDevice(&prev));
+        if (prev != dev) { HIPC(hipSetDevice(dev)); changed = true; }
+    }
+    ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // device memory helpers (library-owned buffers)
@@ -132,12 +145,36 @@ static Profiler g_prof;
 
 template <int TM, int EPI, int MODE>
 static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)cgemm_kernel<TM, EPI, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        attr_done = true;
-    }
     hipLaunchKernelGGL((cgemm_kernel<TM, EPI, MODE>), grid, dim3(CG_THREADS), lds, st, p);
+}
+
+// Dynamic-LDS limits are a per-DEVICE function attribute: set them for every kernel instantiation once per device
+// (ucdir_create / ucdir_predictor_create / the single-operator entry points call this on the device they run on).
+template <typename K> static void set_lds_attr(K* k, int bytes) {
+    HIPC(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+template <int TM> static void set_cgemm_attrs() {
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_DOWN>, 100 * 1024);
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_UP>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_PLAIN>, 100 * 1024);
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024);
+}
+static void ensure_kernel_attrs() {
+    static std::set<int> done;
+    int dev = 0;
+    HIPC(hipGetDevice(&dev));
+    if (done.count(dev)) return;
+    set_cgemm_attrs<64>(); set_cgemm_attrs<128>();
+    set_lds_attr(conv3x3_halo_kernel<128, false>, hc_lds_bytes<128>());
+    set_lds_attr(conv3x3_halo_kernel<64, false>, hc_lds_bytes<64>());
+    set_lds_attr(conv3x3_halo_kernel<64, true>, hc_lds_bytes<64>());
+    set_lds_attr(akgm_halo_kernel<false>, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
+    set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS); set_lds_attr(akgm_pre_kernel<16>, AkPre<16>::LDS);
+    set_lds_attr(final_conv_kernel, 160 * 1024);
+    set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
+    set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
+    set_lds_attr(flash_attn_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn_kernel<3, true>, fa_lds_bytes(384));
+    set_lds_attr(flash_attn_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn_kernel<4, true>, fa_lds_bytes(512));
+    done.insert(dev);
 }
 
 // algorithmic work of one launch: 2*MAC of the un-padded problem; bytes = operands read once + output once
@@ -201,7 +238,6 @@ static void launch_cgemm_impl(const GemmP& p, int TM, int epi, hipStream_t st) {
     HIPC(hipGetLastError());
 }
 
-static void set_kernel_attrs() {}
 
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
@@ -218,6 +254,9 @@ static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats =
 
 // pick the th x tw pixel tile (th*tw <= 256, halo <= 324 px) with the best MFMA-slot utilisation
 static void choose_tile(int H, int W, int& th, int& tw) {
+    static std::map<std::pair<int, int>, std::pair<int, int>> memo;       // ~16k candidates: once per (H, W), not per launch
+    auto it = memo.find({H, W});
+    if (it != memo.end()) { th = it->second.first; tw = it->second.second; return; }
     double best = -1; th = 16; tw = 16;
     for (int a = 1; a <= 64; ++a)
         for (int b = 4; b <= 256; ++b) {
@@ -226,15 +265,11 @@ static void choose_tile(int H, int W, int& th, int& tw) {
             const double util = (double)H * W / (tiles * 256.0) - 1e-4 * (a + 2) * (b + 2) / 324.0;
             if (util > best) { best = util; th = a; tw = b; }
         }
+    memo[{H, W}] = {th, tw};
 }
 
 template <int TM, bool DUAL = false>
 static void launch_halo(const GemmP& p, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TM, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, hc_lds_bytes<TM>()));
-        attr_done = true;
-    }
     const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1);
     if (g_prof.on) {
         ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0) + (DUAL ? 2 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
@@ -335,26 +370,14 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
 }
 
 // halo-tile AKGM kernel (akgm_halo.hip.h): 8 / 16 / 32 / 64 channels per group
-static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
-        HIPC(hipFuncSetAttribute((const void*)akgm_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS));
-        HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<8>::LDS));
-        HIPC(hipFuncSetAttribute((const void*)akgm_pre_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, AkPre<16>::LDS));
-        attr_done = true;
-    }
+// tcbuf: caller-owned fold-table scratch of at least y.B * 9 * 8 * C floats (the context plans one; nothing is
+// allocated on the launch path, so a forward can be captured into a HIP graph)
+static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, float* tcbuf, hipStream_t st) {
     // resident-weights kernel: on by default for 8 channels per group (288^2 level, -5 % vs the ring kernel in same-box
     // A/B); for 16 per group it measured +7 % slower (exposed reload of unit 1), so it stays opt-in (UCDIR_PRE16)
     static const bool use_pre = !getenv("UCDIR_NO_PRE"), use_pre16 = getenv("UCDIR_PRE16") != nullptr;
     const bool pre = use_pre && w.Apre != nullptr && (w.cg == 8 || use_pre16);
-    // fold-table scratch, one per stream: launches on different streams (two contexts side by side) must not share it
-    struct TcBuf { float* p = nullptr; size_t cap = 0; };
-    static std::map<hipStream_t, TcBuf> tcbufs;
-    TcBuf& tb = tcbufs[st];
-    const size_t need = (size_t)y.B * 9 * 8 * w.C * sizeof(float);
-    if (need > tb.cap) { if (tb.p) { HIPC(hipStreamSynchronize(st)); (void)hipFree(tb.p); } HIPC(hipMalloc((void**)&tb.p, need)); tb.cap = need; }
-    float* tcbuf = tb.p;
+    require(tcbuf != nullptr, "AKGM: no fold-table scratch");
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
     hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf);
     AkgmHP p;
@@ -411,10 +434,10 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
 
 // AKGM tail of a block: y = swish(sum_s spdyconv(GN2(h1))[c,s] * G[s] * attw[s]) + res
 static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y,
-                     hipStream_t st) {
+                     float* tcbuf, hipStream_t st) {
     const int C = w.C;
     require(C == 64 || C % 128 == 0, "AKGM: channel count must be 64 or a multiple of 128");
-    if (g_use_halo && (w.cg == 8 || w.cg == 16 || w.cg == 32 || w.cg == 64)) { run_akgm_halo(w, h1, G, attw, res, y, st); return; }
+    if (g_use_halo && (w.cg == 8 || w.cg == 16 || w.cg == 32 || w.cg == 64)) { run_akgm_halo(w, h1, G, attw, res, y, tcbuf, st); return; }
     require(w.Kpad != 640, "AKGM weights packed for the halo kernel");
     GemmP p; zero_gemm(p);
     const int TM = (C == 64) ? 64 : 128;
@@ -440,18 +463,30 @@ static void run_akgm(const AkgmW& w, const Act& h1, const float* G, const float*
 }
 
 struct AttnBufs {
-    bf16_t* qkv = nullptr;   // [B][N][3C]
-    float* S = nullptr;      // [B][N][Npad]
-    bf16_t* P = nullptr;     // [B][N][Npad]
+    bf16_t* qkv = nullptr;   // [B][N][3C]  (bf16, or IEEE half when `half`)
+    float* S = nullptr;      // [B][N][Npad]   (materialised-score path only)
+    bf16_t* P = nullptr;     // [B][N][Npad]   (materialised-score path only)
     bf16_t* Vt = nullptr;    // [B][C][Npad]
     int N = 0, Npad = 0, C = 0, B = 0;
+    bool flash = true, half = false;
 };
 
-static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C) {
+static int g_flash = -1;            // -1: environment (UCDIR_NO_FLASH), 0 / 1: ucdir_debug_flag("flash", v)
+static bool flash_ok(int C) {
+    static const bool env_on = !getenv("UCDIR_NO_FLASH");
+    const bool on = g_flash < 0 ? env_on : g_flash != 0;
+    return on && C % 128 == 0 && C <= 512;
+}
+
+static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C, bool half) {
     a.B = B; a.N = N; a.C = C; a.Npad = ((N + 63) / 64) * 64;
+    a.half = half; a.flash = flash_ok(C);
+    require(a.flash || !half, "fp16 attention operands need the flash kernel (C % 128 == 0, C <= 512)");
     a.qkv = (bf16_t*)pool.alloc((size_t)B * N * 3 * C * 2);
-    a.S = (float*)pool.alloc((size_t)B * N * a.Npad * 4);
-    a.P = (bf16_t*)pool.alloc((size_t)B * N * a.Npad * 2);
+    if (!a.flash) {
+        a.S = (float*)pool.alloc((size_t)B * N * a.Npad * 4);
+        a.P = (bf16_t*)pool.alloc((size_t)B * N * a.Npad * 2);
+    }
     a.Vt = (bf16_t*)pool.alloc((size_t)B * C * a.Npad * 2);
 }
 
@@ -491,11 +526,50 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         p.fold = 1; p.stats0 = x.stats; p.inv_count = 1.0 / ((double)C * N);
         p.Tb = wqkv.Tb; p.Tg = wqkv.Tg; p.tab_ld = 3 * C; p.bias = nullptr;
         p.out = a.qkv; p.out_bstride = (long long)N * 3 * C; p.out_ld = 3 * C; p.out_compact = 1; p.nfeat = 3 * C;
+        p.out_f16 = a.half ? 1 : 0;
         launch_cgemm(p, 128, EPI_STD, st);
     }
     // 2. V^T [B][C][Npad]
     hipLaunchKernelGGL(transpose_v_kernel, dim3((Npad + 31) / 32, C / 32, B), dim3(256), 0, st,
                        a.qkv, N, 3 * C, 2 * C, C, Npad, a.Vt);
+    if (a.flash) {
+        // 3. one kernel: QK^T -> online softmax -> P V' + bias + x, GroupNorm statistics of y (flash_attn.hip.h)
+        FlashP f;
+        f.qkv = a.qkv; f.qkv_bstride = (long long)N * 3 * C; f.ld = 3 * C;
+        f.vt = a.Vt; f.vt_bstride = (long long)C * Npad; f.Npad = Npad;
+        f.N = N; f.C = C; f.W = x.W;
+        f.scale_log2e = 1.4426950408889634f / sqrtf((float)C);
+        f.bias = wout.bias;
+        f.res = x.p; f.res_bstride = x.bstride(); f.out = y.p; f.out_bstride = y.bstride();
+        f.stats_out = y.stats;
+        f.nq = (N + FA_BQ - 1) / FA_BQ;
+        const dim3 grid((unsigned)(B * f.nq));
+        const size_t lds = fa_lds_bytes(C);
+        auto launch = [&]() {
+            switch (C / 128 * 2 + (a.half ? 1 : 0)) {
+                case 2: hipLaunchKernelGGL((flash_attn_kernel<1, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 3: hipLaunchKernelGGL((flash_attn_kernel<1, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 4: hipLaunchKernelGGL((flash_attn_kernel<2, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 5: hipLaunchKernelGGL((flash_attn_kernel<2, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 6: hipLaunchKernelGGL((flash_attn_kernel<3, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 7: hipLaunchKernelGGL((flash_attn_kernel<3, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                case 8: hipLaunchKernelGGL((flash_attn_kernel<4, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                default: hipLaunchKernelGGL((flash_attn_kernel<4, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+            }
+        };
+        if (g_prof.on) {
+            ProfEntry e; e.key = 130 + (a.half ? 1 : 0); e.flops = 4.0 * (double)N * N * C * B;
+            e.bytes = ((double)N * 3 * C * 2 + 2.0 * N * C * 2) * B;
+            e.dH = x.H; e.dW = x.W; e.dCin = C; e.dCout = C;
+            e.e0 = g_prof.get(); e.e1 = g_prof.get();
+            HIPC(hipEventRecord(e.e0, st));
+            launch();
+            HIPC(hipEventRecord(e.e1, st));
+            g_prof.entries.push_back(e);
+        } else launch();
+        HIPC(hipGetLastError());
+        return;
+    }
     // 3. S[i][j] = q_i . k_j / sqrt(C)   (rows = keys j, cols = queries i)
     {
         GemmP p; zero_gemm(p);
@@ -623,8 +697,20 @@ struct ucdir_ctx {
     std::vector<LayerRT> rt;
     AttnBufs attn;
     float* attw = nullptr;              // [nblocks][B][8]
+    float* tcbuf = nullptr;             // AKGM fold-table scratch [B][9][8 * max C] (akgm_tc_kernel)
     bool guide_ready = false;
     double flops = 0;
+    // HIP-graph replay of one forward (B = 1 / -p val latency path): captured once per (cond, x_t, level, eps) pointer
+    // set on a library-owned stream, replayed on the caller's stream.  Dropped whenever weights or shapes change.
+    bool use_graph = false;
+    struct FwdGraph { const void *cond, *xt, *lvl, *eps; hipGraph_t g; hipGraphExec_t ex; };
+    std::vector<FwdGraph> graphs;
+    hipStream_t cap_stream = nullptr;
+    void drop_graphs() {
+        for (auto& f : graphs) { (void)hipGraphExecDestroy(f.ex); (void)hipGraphDestroy(f.g); }
+        graphs.clear();
+    }
+    ~ucdir_ctx() { drop_graphs(); if (cap_stream) (void)hipStreamDestroy(cap_stream); }
 };
 
 static std::vector<std::string> expected_names(const ucdir_config& c, const std::vector<LayerDesc>& L) {
@@ -796,8 +882,13 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     fl += 2.0 * 9 * c->cfg.inner_channel * c->cfg.channel_mults[0] * c->cfg.out_channel * c->Hc * c->Wc;
     c->flops = fl * B;
     c->fin_act = make_act(c->apool, B, c->Hc, c->Wc, c->cfg.inner_channel * c->cfg.channel_mults[0], false);
-    if (maxN > 0) alloc_attn(c->apool, c->attn, B, maxN, attC);
+    if (maxN > 0) alloc_attn(c->apool, c->attn, B, maxN, attC, c->cfg.attn_fp16 != 0);
     c->attw = (float*)c->apool.alloc((size_t)c->nblocks * B * 8 * sizeof(float));
+    {
+        int maxC = 0;
+        for (const auto& d : c->layers) if (d.kind == "block" && d.cout > maxC) maxC = d.cout;
+        c->tcbuf = (float*)c->apool.alloc((size_t)B * 9 * 8 * maxC * sizeof(float), false);
+    }
     c->guide_ready = false;
 }
 
@@ -836,7 +927,7 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
             const Act* res = x0;
             if (w.has_res) { if (!res_done) run_conv(w.resconv, *x0, x1, r.res, COLS_S1, 0, nullptr, false, st); res = &r.res; }
             Act& bo = d.attn ? r.bo : r.out;
-            run_akgm(w.sp, r.h1, r.G, c->attw + (size_t)w.block_index * B * 8, *res, bo, st);
+            run_akgm(w.sp, r.h1, r.G, c->attw + (size_t)w.block_index * B * 8, *res, bo, c->tcbuf, st);
             if (d.attn) run_attention(w.qkv, w.outp, bo, r.out, c->attn, st);
         }
         cur = &r.out;
@@ -851,11 +942,6 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
             const dim3 grid((c->Wc + 15) / 16, (c->Hc + 15) / 16, B);
             const size_t lds = (size_t)324 * 80 + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C;
             require(lds <= 160 * 1024, "final conv: channel count too large for the fused kernel");
-            static bool attr_done = false;
-            if (!attr_done) {
-                HIPC(hipFuncSetAttribute((const void*)final_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done = true;
-            }
             hipLaunchKernelGGL(final_conv_kernel, grid, dim3(256), lds, st, cur->p, c->Hc, c->Wc, C, cur->stats,
                                1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b, co, eps, c->H, c->W);
             HIPC(hipGetLastError());
@@ -867,6 +953,26 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
             run_conv(c->fin_conv, c->fin_act, nullptr, dummy, COLS_S1, 0, nullptr, false, st, eps, c->H, c->W);
         }
     }
+}
+
+// One forward as a HIP-graph replay: the launch sequence of forward() depends only on the planned shape and on the
+// four tensor pointers, so it is captured once per pointer set (the sampler keeps x_t, eps and the level in persistent
+// buffers) and replayed: ~150 kernel launches become one hipGraphLaunch.  Capture runs on a library-owned stream (the
+// legacy default stream cannot be captured); nothing on the launch path allocates or synchronises.
+static void forward_graph(ucdir_ctx* c, const float* cond, const float* xt, const float* level, float* eps, hipStream_t st) {
+    for (auto& f : c->graphs)
+        if (f.cond == cond && f.xt == xt && f.lvl == level && f.eps == eps) { HIPC(hipGraphLaunch(f.ex, st)); return; }
+    if (c->graphs.size() >= 8) c->drop_graphs();                 // callers that keep changing pointers: bounded cache
+    if (!c->cap_stream) HIPC(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPC(hipStreamSynchronize(st));                              // inputs produced on the caller's stream are complete
+    ucdir_ctx::FwdGraph f{cond, xt, level, eps, nullptr, nullptr};
+    HIPC(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    try { forward(c, cond, xt, level, eps, c->cap_stream); }
+    catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(c->cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    HIPC(hipStreamEndCapture(c->cap_stream, &f.g));
+    HIPC(hipGraphInstantiate(&f.ex, f.g, nullptr, nullptr, 0));
+    c->graphs.push_back(f);
+    HIPC(hipGraphLaunch(f.ex, st));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -885,8 +991,9 @@ int32_t ucdir_create(const ucdir_config* cfg, ucdir_ctx** out) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     require(e == hipSuccess && ndev > 0, "no HIP device available (libucdir_hip has no CPU fallback)");
-    HIPC(hipSetDevice(cfg->device));
-    set_kernel_attrs();
+    require(cfg->device >= 0 && cfg->device < ndev, "bad device ordinal");
+    DevGuard dg(cfg->device);
+    ensure_kernel_attrs();
     std::unique_ptr<ucdir_ctx> c(new ucdir_ctx());
     c->cfg = *cfg;
     c->layers = build_layers(*cfg);
@@ -897,7 +1004,10 @@ int32_t ucdir_create(const ucdir_config* cfg, ucdir_ctx** out) {
     API_END
 }
 
-void ucdir_destroy(ucdir_ctx* ctx) { delete ctx; }
+void ucdir_destroy(ucdir_ctx* ctx) {
+    if (!ctx) return;
+    try { DevGuard dg(ctx->cfg.device); ctx->drop_graphs(); delete ctx; } catch (...) {}
+}
 
 int32_t ucdir_num_weights(const ucdir_ctx* ctx) { return ctx ? (int32_t)ctx->wnames.size() : 0; }
 const char* ucdir_weight_name(const ucdir_ctx* ctx, int32_t i) {
@@ -919,7 +1029,8 @@ int32_t ucdir_load_weight(ucdir_ctx* ctx, const char* name, const float* data_ho
 int32_t ucdir_finalize_weights(ucdir_ctx* ctx) {
     API_BEGIN
     require(ctx, "null ctx");
-    HIPC(hipSetDevice(ctx->cfg.device));
+    DevGuard dg(ctx->cfg.device);
+    ctx->drop_graphs();
     for (const auto& n : ctx->wnames) require(ctx->host.count(n) == 1, "missing weight: " + n);
     finalize_weights(ctx);
     HIPC(hipDeviceSynchronize());
@@ -930,9 +1041,11 @@ int32_t ucdir_prepare_guide(ucdir_ctx* ctx, const float* guide, int32_t B, int32
     API_BEGIN
     require(ctx && guide, "null argument");
     require(ctx->finalized, "weights not finalized");
+    DevGuard dg(ctx->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     if (B != ctx->B || H != ctx->H || W != ctx->W || pad_mode != ctx->pad_mode || ctx->rt.empty()) {
         HIPC(hipStreamSynchronize(st));
+        ctx->drop_graphs();
         plan_shapes(ctx, B, H, W, pad_mode);
         HIPC(hipDeviceSynchronize());
     }
@@ -949,10 +1062,27 @@ int32_t ucdir_prepare_guide(ucdir_ctx* ctx, const float* guide, int32_t B, int32
     API_END
 }
 
-int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t, const float* noise_level, float* eps, void* stream) {
+int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t, const float* noise_level, float* eps,
+                           int32_t B, int32_t H, int32_t W, void* stream) {
     API_BEGIN
     require(ctx && cond && x_t && noise_level && eps, "null argument");
-    forward(ctx, cond, x_t, noise_level, eps, (hipStream_t)stream);
+    require(B == ctx->B && H == ctx->H && W == ctx->W,
+            "ucdir_unet_forward: (B,H,W) = (" + std::to_string(B) + "," + std::to_string(H) + "," + std::to_string(W) +
+            ") does not match the shape planned by ucdir_prepare_guide (" + std::to_string(ctx->B) + "," +
+            std::to_string(ctx->H) + "," + std::to_string(ctx->W) + ")");
+    DevGuard dg(ctx->cfg.device);
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->use_graph && !g_prof.on) forward_graph(ctx, cond, x_t, noise_level, eps, st);
+    else forward(ctx, cond, x_t, noise_level, eps, st);
+    API_END
+}
+
+int32_t ucdir_set_graph(ucdir_ctx* ctx, int32_t on) {
+    API_BEGIN
+    require(ctx, "null ctx");
+    DevGuard dg(ctx->cfg.device);
+    ctx->use_graph = on != 0;
+    if (!on) ctx->drop_graphs();
     API_END
 }
 
@@ -960,6 +1090,10 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
                            float coef1, float coef2, float sigma, void* stream) {
     API_BEGIN
     require(x_t && eps, "null argument");
+    hipPointerAttribute_t pa;
+    HIPC(hipPointerGetAttributes(&pa, x_t));
+    require(pa.type == hipMemoryTypeDevice, "ucdir_sampler_step: x_t is not a device pointer");
+    DevGuard dg(pa.device);
     long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, eps,
                        sigma != 0.f ? noise : nullptr, (long long)n, c_recip, c_recipm1, coef1, coef2, sigma);
@@ -970,6 +1104,7 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
 int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst, int64_t dst_elems, void* stream) {
     API_BEGIN
     require(ctx && layer && what && dst, "null argument");
+    DevGuard dg(ctx->cfg.device);
     for (size_t li = 0; li < ctx->layers.size(); ++li) {
         if (ctx->layers[li].name != layer) continue;
         const LayerRT& r = ctx->rt[li];
@@ -985,6 +1120,14 @@ int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, fl
         return 0;
     }
     throw std::runtime_error(std::string("unknown layer ") + layer);
+    API_END
+}
+
+int32_t ucdir_debug_flag(const char* name, int32_t value) {
+    API_BEGIN
+    require(name != nullptr, "null argument");
+    if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
+    else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END
 }
 
@@ -1038,7 +1181,7 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
                       int32_t cout, int32_t ksize, int32_t mode, int32_t silu, const float* residual, float* y,
                       double* stats_out_host, void* stream) {
     API_BEGIN
-    set_kernel_attrs();
+    ensure_kernel_attrs();
     hipStream_t st = (hipStream_t)stream;
     DevPool pool;
     Act a0 = act_from_nchw(pool, x0, B, c0, H, W, st, true);
@@ -1069,7 +1212,7 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_
                       const float* wsp_host, const float* bsp_host, const float* gamma_host, const float* beta_host,
                       float* y, void* stream) {
     API_BEGIN
-    set_kernel_attrs();
+    ensure_kernel_attrs();
     hipStream_t st = (hipStream_t)stream;
     DevPool pool;
     Act ah = act_from_nchw(pool, h, B, C, H, W, st, true);
@@ -1080,7 +1223,8 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_
     std::vector<float> ones((size_t)B * 8, 1.f);
     float* attw = pool.upload(ones);
     AkgmW w = upload_akgm(pool, wsp_host, bsp_host, gamma_host, beta_host, C);
-    run_akgm(w, ah, G, attw, ar, out, st);
+    float* tcbuf = (float*)pool.alloc((size_t)B * 9 * 8 * C * sizeof(float), false);
+    run_akgm(w, ah, G, attw, ar, out, tcbuf, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(st));
@@ -1089,14 +1233,14 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_
 
 int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, const float* gamma_host,
                            const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
-                           float* y, void* stream) {
+                           int32_t fp16, float* y, void* stream) {
     API_BEGIN
-    set_kernel_attrs();
+    ensure_kernel_attrs();
     hipStream_t st = (hipStream_t)stream;
     DevPool pool;
     Act ax = act_from_nchw(pool, x, B, C, H, W, st, true);
     Act out = make_act(pool, B, H, W, C);
-    AttnBufs ab; alloc_attn(pool, ab, B, H * W, C);
+    AttnBufs ab; alloc_attn(pool, ab, B, H * W, C, fp16 != 0);
     const std::vector<float> wf = fold_out_into_v(wqkv_host, wout_host, C);
     ConvW wq = upload_conv(pool, wf.data(), nullptr, gamma_host, beta_host, 3 * C, C, 1);
     ConvW wo = upload_conv(pool, wout_host, bout_host, nullptr, nullptr, C, C, 1);
@@ -1285,13 +1429,18 @@ int32_t ucdir_predictor_create(int32_t device, ucdir_predictor** out) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     require(e == hipSuccess && ndev > 0, "no HIP device available (libucdir_hip has no CPU fallback)");
-    HIPC(hipSetDevice(device));
+    require(device >= 0 && device < ndev, "bad device ordinal");
+    DevGuard dg(device);
+    ensure_kernel_attrs();
     std::unique_ptr<ucdir_predictor> c(new ucdir_predictor());
     c->device = device;
     *out = c.release();
     API_END
 }
-void ucdir_predictor_destroy(ucdir_predictor* p) { delete p; }
+void ucdir_predictor_destroy(ucdir_predictor* p) {
+    if (!p) return;
+    try { DevGuard dg(p->device); delete p; } catch (...) {}
+}
 
 int32_t ucdir_predictor_load_weight(ucdir_predictor* p, const char* name, const float* data_host, const int64_t* shape, int32_t ndim) {
     API_BEGIN
@@ -1307,7 +1456,7 @@ int32_t ucdir_predictor_load_weight(ucdir_predictor* p, const char* name, const 
 int32_t ucdir_predictor_finalize(ucdir_predictor* p) {
     API_BEGIN
     require(p, "null argument");
-    HIPC(hipSetDevice(p->device));
+    DevGuard dg(p->device);
     predictor_finalize(p);
     HIPC(hipDeviceSynchronize());
     API_END
@@ -1317,6 +1466,7 @@ int32_t ucdir_predictor_forward(ucdir_predictor* p, const float* x, float* y, in
     API_BEGIN
     require(p && x && y, "null argument");
     require(p->finalized, "predictor weights not finalized");
+    DevGuard dg(p->device);
     hipStream_t st = (hipStream_t)stream;
     if (B != p->B || H != p->H || W != p->W) {
         HIPC(hipStreamSynchronize(st));

@@ -13,7 +13,12 @@ Differences from the reference, all result-preserving:
   * the point-wise update runs as one fused HIP kernel (``ucdir_sampler_step``);
   * ``cat([cond, x_t])`` is not materialised;
   * batches: the reference's ``ret_img[-1]`` is only correct for B = 1; here a
-    batch is B independent restorations and the non-``continous`` result is (B,3,H,W).
+    batch is B independent restorations and the non-``continous`` result is (B,3,H,W);
+  * ``p_sample_loop`` keeps x_t, eps and the noise level in persistent buffers and updates x_t in place, so
+    the denoiser sees the same pointers every step (HIP-graph replay, ``DY3h.set_graph``);
+  * ``noise_seed``: when set, x_T and the per-step noise come from a device generator seeded with it at the
+    start of every loop - identical on every rank, which the sharded patch split needs (every rank applies
+    the same sampler update to the gathered eps).
 """
 from functools import partial
 
@@ -56,6 +61,8 @@ class GaussianDiffusion(nn.Module):
         self.loss_type = loss_type
         self.conditional = conditional
         self.noise_source = None     # optional callable(shape, device, k) -> tensor, for injected noise
+        self.noise_seed = None       # optional int: rank-identical device generator (sharded patch split)
+        self._gen = None
 
     def set_loss(self, device):
         if self.loss_type == "l1":
@@ -103,7 +110,21 @@ class GaussianDiffusion(nn.Module):
     def _noise(self, like, k):
         if self.noise_source is not None:
             return self.noise_source(like.shape, like.device, k)
+        if self._gen is not None:
+            return torch.randn(like.shape, generator=self._gen, device=like.device, dtype=like.dtype)
         return torch.randn_like(like)
+
+    def _start_noise(self, device):
+        """(Re)seed the rank-identical generator at the start of a sampling loop."""
+        self._gen = None
+        if self.noise_seed is not None and self.noise_source is None:
+            self._gen = torch.Generator(device=device)
+            self._gen.manual_seed(int(self.noise_seed))
+
+    def _eps(self, cond, x, lvl, guide, out=None):
+        if self._small(x):
+            return self.denoise_fn.forward_split(cond, x, lvl, guide, out=out)
+        return self.denoise_fn(torch.cat([cond, x], dim=1), lvl, guide)
 
     @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=True, condition_x=None, kwargs={}, _k=None):
@@ -113,8 +134,7 @@ class GaussianDiffusion(nn.Module):
         lvl = torch.full((B, 1), level, dtype=torch.float32, device=x.device)
         guide = kwargs.get("guide")
         if condition_x is not None:
-            eps = self.denoise_fn.forward_split(condition_x, x, lvl, guide) if self._small(x) else \
-                self.denoise_fn(torch.cat([condition_x, x], dim=1), lvl, guide)
+            eps = self._eps(condition_x, x, lvl, guide)
         else:
             raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
         noise = self._noise(x, _k) if t > 0 else None
@@ -129,17 +149,41 @@ class GaussianDiffusion(nn.Module):
         """model/diffusion.py:185-211, conditional branch."""
         if not self.conditional:
             raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
-        x = x_in
+        x = x_in.contiguous().float()
         sample_inter = 1 | (self.num_timesteps // 10)
-        img = self._noise(x, 0)
+        self._start_noise(x.device)
+        guide = kwargs.get("guide")
+        B = x.shape[0]
+        if getattr(self.denoise_fn, "use_graph", False) and self._small(x):
+            # graph replay: the four tensors the denoiser sees live in buffers that persist ACROSS restorations of the
+            # same shape, so the forward is captured once and replayed for every step of every image
+            key = (tuple(x.shape), x.device)
+            bufs = getattr(self, "_graph_bufs", None)
+            if bufs is None or bufs[0] != key:
+                bufs = (key, torch.empty_like(x), torch.empty_like(x), torch.empty_like(x),
+                        torch.empty((B, 1), dtype=torch.float32, device=x.device))
+                self._graph_bufs = bufs
+            _, cond, img, eps_buf, lvl = bufs
+            cond.copy_(x)
+            img.copy_(self._noise(x, 0))
+        else:
+            cond = x
+            img = self._noise(x, 0).clone()                   # x_t: ONE buffer, updated in place
+            eps_buf = torch.empty_like(img)
+            lvl = torch.empty((B, 1), dtype=torch.float32, device=x.device)
         ret = [x]
         k = 1
         for i in reversed(range(self.num_timesteps)):
-            img = self.p_sample(img, i, condition_x=x, kwargs=kwargs, _k=k)
+            level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
+            lvl.fill_(level)
+            eps = self._eps(cond, img, lvl, guide, out=eps_buf)
+            noise = self._noise(img, k) if i > 0 else None
+            sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
             if i > 0:
                 k += 1
             if i % sample_inter == 0:
-                ret.append(img)
+                ret.append(img.clone())
+        self._gen = None
         if continous:
             return torch.cat(ret, dim=0)
         return ret[-1]
@@ -153,6 +197,7 @@ class GaussianDiffusion(nn.Module):
         times = list(reversed(times.int().tolist()))
         pairs = list(zip(times[:-1], times[1:]))
         ac = self._host_tables["alphas_cumprod"]
+        self._start_noise(x_in.device)
         img = self._noise(x_in, 0)
         imgs = [img]
         guide = kwargs.get("guide")
@@ -160,8 +205,7 @@ class GaussianDiffusion(nn.Module):
         for t, t_next in pairs:
             level, c_recip, c_recipm1, _, _, _ = self.step_coefficients(t)
             lvl = torch.full((x_in.shape[0], 1), level, dtype=torch.float32, device=x_in.device)
-            eps = self.denoise_fn.forward_split(x_in, img, lvl, guide) if self._small(img) else \
-                self.denoise_fn(torch.cat([x_in, img], dim=1), lvl, guide)
+            eps = self._eps(x_in, img, lvl, guide)
             x0 = (c_recip * img - c_recipm1 * eps).clamp_(-1.0, 1.0)
             if t_next < 0:
                 img = x0
@@ -188,10 +232,9 @@ class GaussianDiffusion(nn.Module):
 
         def model_eps(x, t):
             lvl = torch.full((B, 1), ns.model_input_time(t), dtype=torch.float32, device=x_in.device)
-            if self._small(x):
-                return self.denoise_fn.forward_split(x_in, x, lvl, guide)
-            return self.denoise_fn(torch.cat([x_in, x], dim=1), lvl, guide)
+            return self._eps(x_in, x, lvl, guide)
 
+        self._start_noise(x_in.device)
         return D.sample(model_eps, ns, self._noise(x_in, 0), steps=steps, order=order)
 
     @torch.no_grad()

@@ -10,6 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCDIR_LIB") or os.path.join(_HERE, "libucdir_hip.so")   # UCDIR_LIB: A/B-test another build
 MAX_MULTS = 8
+ABI_VERSION = 2
 
 
 class UcdirConfig(Structure):
@@ -17,7 +18,7 @@ class UcdirConfig(Structure):
         ("in_channel", c_int32), ("out_channel", c_int32), ("inner_channel", c_int32),
         ("n_mults", c_int32), ("channel_mults", c_int32 * MAX_MULTS),
         ("n_attn_res", c_int32), ("attn_res", c_int32 * MAX_MULTS),
-        ("res_blocks", c_int32), ("image_size", c_int32), ("device", c_int32),
+        ("res_blocks", c_int32), ("image_size", c_int32), ("device", c_int32), ("attn_fp16", c_int32),
     ]
 
 
@@ -35,11 +36,13 @@ _SIGS = {
     "ucdir_num_weights": (c_int32, [c_void_p]),
     "ucdir_weight_name": (c_char_p, [c_void_p, c_int32]),
     "ucdir_prepare_guide": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "ucdir_unet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ucdir_unet_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ucdir_set_graph": (c_int32, [c_void_p, c_int32]),
     "ucdir_sampler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                      c_float, c_void_p]),
     "ucdir_debug_read": (c_int32, [c_void_p, c_char_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "ucdir_workspace_bytes": (c_int64, [c_void_p]),
+    "ucdir_debug_flag": (c_int32, [c_char_p, c_int32]),
     "ucdir_profile_enable": (c_int32, [c_int32]),
     "ucdir_profile_read": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), POINTER(c_double),
                                      POINTER(c_double), POINTER(c_int32), c_void_p]),
@@ -55,7 +58,7 @@ _SIGS = {
     "ucdir_op_akgm": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "ucdir_op_attention": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
 }
 EXPORTED = tuple(_SIGS)
 
@@ -76,7 +79,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.ucdir_abi_version() != 1:
+    if lib.ucdir_abi_version() != ABI_VERSION:
         raise UcdirError("libucdir_hip ABI version mismatch")
     _lib = lib
     return lib

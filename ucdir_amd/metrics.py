@@ -9,6 +9,17 @@ import math
 import numpy as np
 
 
+def tensor2img_u8_device(tensor, min_max=(-1, 1)):
+    """tensor2img for ONE image that lives on the GPU: clamp / rescale / round / HWC on the device, then a uint8 copy
+    (4x fewer bytes over PCIe than the reference's fp32 ``.cpu()``; same arithmetic, same rounding: torch.round and
+    numpy.round are both round-half-to-even)."""
+    t = tensor.detach().squeeze().float().clamp(*min_max)
+    t = (t - min_max[0]) / (min_max[1] - min_max[0])
+    if t.dim() != 3:
+        raise ValueError("tensor2img_u8_device takes one (3,H,W) image")
+    return (t * 255.0).round().to(__import__("torch").uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+
+
 def tensor2img(tensor, out_type=np.uint8, min_max=(-1, 1)):
     """core/metrics.py:8-34 for 3-D / single-image 4-D tensors: clamp, rescale to [0,1], HWC, round to uint8."""
     t = tensor.squeeze().float().cpu().clamp(*min_max)

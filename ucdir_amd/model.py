@@ -4,6 +4,11 @@ Only the inference surface ``sr.py -p val`` uses: device placement, EMA checkpoi
 ``feed_data`` / ``test`` (reflect-pad 64, restore, crop; model/model.py:124-138),
 ``set_new_noise_schedule`` and ``get_current_visuals``.  One process per GPU; no DDP wrapper is
 needed for sampling (the reference's wrapper only broadcasts parameters).
+
+Multi-GPU (``torch.distributed`` initialised, world size > 1): images whose padded area exceeds the
+denoiser's patch threshold have the windows of every step sharded over the ranks of ``patch_group``
+(default: the world group) with one all-gather per step; all ranks draw identical noise from
+``noise_seed`` so the sampler update needs no second exchange (utils/util.py:108-146).
 """
 import logging
 import os
@@ -26,6 +31,16 @@ class DDPM:
         self.netG.set_loss(self.device)
         self.set_new_noise_schedule(opt["model"]["beta_schedule"]["train"], schedule_phase="train")
         self.load_network()
+        self.setup_distributed()
+
+    def setup_distributed(self, group=None, noise_seed=1234):
+        """Shard the patch-split windows over the ranks of ``group`` (default: world) when running multi-process."""
+        import torch.distributed as dist
+        if group is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        g = group if group is not None else dist.group.WORLD
+        self.netG.denoise_fn.patch_group = g
+        self.netG.noise_seed = noise_seed          # every rank must apply the identical sampler update
 
     def feed_data(self, data):
         self.data = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
@@ -51,6 +66,16 @@ class DDPM:
         out["LR"] = self.data["LR"].detach().float().cpu() if need_LR and "LR" in self.data else out["INF"]
         return out
 
+    def visuals_u8(self):
+        """uint8 HWC images of the val loop (final SR, HR, LR, INF = predictor output) converted ON THE DEVICE:
+        only 4 x H x W x 3 bytes cross PCIe instead of the 11 fp32 snapshots of get_current_visuals."""
+        from .metrics import tensor2img_u8_device as cv
+        sr = self.SR[-1] if self.SR.dim() == 4 else self.SR
+        out = OrderedDict(SR=cv(sr), HR=cv(self.data["HR"]), LR=cv(self.data["LR"] if "LR" in self.data else self.data["SR"]))
+        pre = getattr(self.netG, "pre_initx", None)
+        out["INF"] = cv(pre[..., 64:-64, 64:-64]) if pre is not None else cv(self.data["SR"])
+        return out
+
     def load_network(self):
         """model/model.py:224-251: in val phase with EMA on, ``{prefix}_gen_ema.pth`` is loaded strict=False."""
         prefix = self.opt["path"]["resume_state"]
@@ -63,9 +88,44 @@ class DDPM:
             raise FileNotFoundError(path)
         logger.info("Loading pretrained model for G [{:s}] ...".format(path))
         sd = torch.load(path, map_location="cpu")
-        # schedule buffers saved at training length (2000) are re-created by set_new_noise_schedule
-        sd = {k: v for k, v in sd.items() if "." in k}
-        self.netG.load_state_dict(sd, strict=False)
+        report = load_checkpoint_state(self.netG, sd, strict=not use_ema and not self.opt["model"].get("finetune_norm"))
+        logger.info("checkpoint %s: %d tensors loaded, %d schedule buffers skipped", path, report["loaded"], len(report["skipped_buffers"]))
+
+
+SCHEDULE_BUFFERS = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                    "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                    "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2")
+
+
+def load_checkpoint_state(netG, sd, strict=False):
+    """``network.load_state_dict`` of model/model.py:236-243 with the result inspected.
+
+    * a leading ``module.`` (DataParallel / DDP wrapper) is stripped;
+    * the twelve schedule buffers (saved at training length, re-created by ``set_new_noise_schedule``) are skipped;
+    * EVERY ``denoise_fn.*`` / ``predictor.*`` parameter of ``netG`` must be present with the right shape and no
+      unknown ``denoise_fn.*`` / ``predictor.*`` key may remain: a checkpoint of another architecture or with renamed
+      keys raises instead of leaving the random initialisation in place (the reference's strict=False is silent);
+    * ``strict`` additionally rejects any other unexpected key (the reference's non-EMA path, strict = not finetune_norm).
+    """
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    skipped = [k for k in sd if k in SCHEDULE_BUFFERS]
+    sd = {k: v for k, v in sd.items() if k not in SCHEDULE_BUFFERS}
+    own = dict(netG.named_parameters())
+    need = [k for k in own if k.startswith(("denoise_fn.", "predictor."))]
+    missing = [k for k in need if k not in sd]
+    bad_shape = [k for k in need if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+    unknown = [k for k in sd if k not in own]
+    unknown_net = [k for k in unknown if k.startswith(("denoise_fn.", "predictor."))]
+    if missing or bad_shape or unknown_net or (strict and unknown):
+        def head(v):
+            return ", ".join(v[:6]) + (" ..." if len(v) > 6 else "")
+        raise RuntimeError("checkpoint does not match the network: missing [%s]; wrong shape [%s]; unexpected [%s]"
+                           % (head(missing), head(bad_shape), head(unknown_net if not strict else unknown)))
+    for k in unknown:
+        logger.warning("checkpoint key ignored: %s", k)
+    res = netG.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+    return {"loaded": len(sd) - len(unknown), "skipped_buffers": skipped, "ignored": unknown,
+            "missing_non_network": list(res.missing_keys)}
 
 
 def create_model(opt, device=None):

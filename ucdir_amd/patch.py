@@ -28,13 +28,26 @@ def patch_pad(H, W, skip, padding):
     return skip - pd + padding if pd < skip else padding
 
 
+_GUIDE_WINDOWS = {}      # the guide does not change over the steps of a restoration: its padded windows are cut once
+
+
+def _guide_chunks(guide, pd, chunks):
+    key = (guide.data_ptr(), guide._version, tuple(guide.shape), pd, tuple(map(tuple, chunks)))
+    hit = _GUIDE_WINDOWS.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    gp = F.pad(guide, (pd, pd, pd, pd), mode="reflect")
+    out = [torch.cat([gp[..., a:b, c:d] for (a, b, c, d) in ch], dim=0).contiguous() for ch in chunks]
+    _GUIDE_WINDOWS["k"] = (key, out, guide)          # one entry; keeps `guide` alive so the key cannot be recycled
+    return out
+
+
 def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, max_batch=8):
     """Same result as the reference's sequential loop; ``net(x, time=..., guide=...)`` is called on
     batches of windows.  noisy (B,6,H,W); params = {'time': (B,1), 'guide': (B,3,H,W)}."""
     B = noisy.shape[0]
     pd = patch_pad(noisy.shape[-2], noisy.shape[-1], skip, padding)
     xp = F.pad(noisy, (pd, pd, pd, pd), mode="reflect")
-    gp = F.pad(params["guide"], (pd, pd, pd, pd), mode="reflect")
     _, _, H, W = xp.shape
     wins = patch_windows(H, W, skip, padding)
     rank, world = 0, 1
@@ -44,13 +57,22 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
     per = (len(wins) + world - 1) // world
     mine = wins[rank * per:(rank + 1) * per]
     outs = []
-    for s in range(0, len(mine), max_batch):
-        chunk = mine[s:s + max_batch]
-        xb = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
-        gb = torch.cat([gp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
-        tb = params["time"].repeat(len(chunk), 1)
-        o = net(xb, tb, gb)
-        outs.append(o[..., padding:-padding, padding:-padding])
+    if mine:
+        # equal chunks, the last one padded with a repeat of its last window: every engine call of every step has the
+        # same batch, so the engine plans its (multi-GB) workspace once instead of re-planning when the batch alternates
+        nchunk = (len(mine) + max_batch - 1) // max_batch
+        size = (len(mine) + nchunk - 1) // nchunk
+        chunks, reals = [], []
+        for s in range(0, len(mine), size):
+            chunk = mine[s:s + size]
+            reals.append(len(chunk))
+            chunks.append(chunk + [chunk[-1]] * (size - len(chunk)))
+        gbs = _guide_chunks(params["guide"], pd, chunks)
+        for chunk, real, gb in zip(chunks, reals, gbs):
+            xb = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
+            tb = params["time"].repeat(len(chunk), 1)
+            o = net(xb, tb, gb)
+            outs.append(o[:real * B, :, padding:-padding, padding:-padding])
     inner = skip - 2 * padding
     if outs:
         local = torch.cat(outs, dim=0)

@@ -6,8 +6,12 @@ checkpoints load with ``load_state_dict``) and call signature
 (reference: model/ucdir.py:204-307), but it has no PyTorch forward: every call goes to the HIP
 engine behind include/ucdir_hip.h.  On a machine without the library or without a GPU it raises.
 
-``UNetSeeInDark`` (the one-shot predictor, model/ucdir.py:310-416) currently runs on stock ATen
-GPU ops; it is 0.13 % of a 50-step restoration (f-rank 1).
+``UNetSeeInDark`` (the one-shot predictor, model/ucdir.py:310-416) runs on the same engine
+(``ucdir_predictor_*``); it is 0.13 % of a 50-step restoration.
+
+Inter-step patch split (model/ucdir.py:298-300 -> utils/util.py:108-146): ``DY3h.forward`` evaluates the
+windows of a step as batches and, when ``patch_group`` is set (``sr.py`` / ``model.DDPM`` set it to the
+world group when WORLD_SIZE > 1), shards them over the ranks with one all-gather per step.
 """
 import ctypes
 import math
@@ -22,8 +26,9 @@ from .patch import patch_forward_guide
 from .spec import UNetConfig, predictor_param_shapes, unet_param_shapes
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None):
+    """Current PyTorch stream of ``device`` (default: the current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -59,10 +64,15 @@ class DY3h(nn.Module):
 
     def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=1, channel_mults=(1, 2, 4, 8, 8),
                  attn_res=(8,), res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=128,
-                 resname="ResnetBlockDY3h"):
+                 resname="ResnetBlockDY3h", attn_dtype="bf16"):
         super().__init__()
         if not with_noise_level_emb or resname != "ResnetBlockDY3h":
             raise NotImplementedError("only the DY3h configuration of config/sid.yaml is implemented")
+        if attn_dtype not in ("bf16", "fp16"):
+            raise ValueError("attn_dtype must be 'bf16' or 'fp16'")
+        # not a reference argument: operand type of the attention MFMAs (q, k, v', P); 'fp16' is the JPEG
+        # configuration's "fp16 attention MFMA path" (BASELINE.json configs[4]); accumulation / softmax stay fp32
+        self.attn_dtype = attn_dtype
         self.cfg = UNetConfig(in_channel=in_channel, out_channel=out_channel, inner_channel=inner_channel,
                               norm_groups=norm_groups, channel_mults=tuple(channel_mults), attn_res=tuple(attn_res),
                               res_blocks=res_blocks, dropout=dropout, image_size=image_size)
@@ -77,9 +87,31 @@ class DY3h(nn.Module):
                 nn.init.uniform_(dict(self.named_parameters())[name], -bound, bound)
         self.patch_threshold = 1024 * 1024   # model/ucdir.py:298
         self.patch_skip, self.patch_padding = 1024, 64
+        self.patch_group = None              # torch.distributed group: windows of a step are sharded over its ranks
+        self.patch_max_batch = 8             # windows per engine call
+        self.use_graph = False               # replay each forward from a HIP graph (B = 1 latency path)
         self._h = None
-        self._wkey = None
+        self._wdirty = True                  # parameters changed since the engine packed them
         self._gkey = None
+
+    # ---- weight-change tracking: O(1) per forward ------------------------------------------------
+    # Every path that replaces or rewrites parameter storage in this repo's scope goes through one of these hooks
+    # (load_state_dict, .to() / .cuda() / .float() via _apply).  Code that mutates ``p.data`` in place must call
+    # ``mark_weights_dirty()``.
+    def mark_weights_dirty(self):
+        self._wdirty = True
+
+    def _apply(self, fn, *a, **k):
+        self._wdirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._wdirty = True
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):       # also reached when a parent module loads
+        self._wdirty = True
+        return super()._load_from_state_dict(*a, **k)
 
     # ---- engine plumbing -------------------------------------------------------------------------
     def _device_index(self):
@@ -101,15 +133,15 @@ class DY3h(nn.Module):
             for i, v in enumerate(cfg.attn_res):
                 c.attn_res[i] = v
             c.res_blocks, c.image_size, c.device = cfg.res_blocks, cfg.image_size, self._device_index()
+            c.attn_fp16 = 1 if self.attn_dtype == "fp16" else 0
             h = ctypes.c_void_p()
             _lib.check(L.ucdir_create(ctypes.byref(c), ctypes.byref(h)))
             self._h = h
         return self._h
 
     def _sync_weights(self):
-        """(Re)pack weights into the engine when parameters changed (load_state_dict, .to, training step)."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if key == self._wkey:
+        """(Re)pack weights into the engine when parameters changed (load_state_dict, .to, mark_weights_dirty)."""
+        if not self._wdirty and self._h is not None:
             return
         L = _lib.load()
         h = self._handle()
@@ -118,33 +150,64 @@ class DY3h(nn.Module):
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
             _lib.check(L.ucdir_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
         _lib.check(L.ucdir_finalize_weights(h))
-        self._wkey = key
+        _lib.check(L.ucdir_set_graph(h, 1 if self.use_graph else 0))
+        self._wdirty = False
         self._gkey = None
+
+    def set_graph(self, on=True):
+        """Replay forwards from a HIP graph captured once per (cond, x_t, level, eps) buffer set."""
+        self.use_graph = bool(on)
+        if self._h is not None:
+            _lib.check(_lib.load().ucdir_set_graph(self._h, 1 if on else 0))
+
+    def _dev(self):
+        return torch.device("cuda", self._device_index())
+
+    def _check_dev(self, name, t):
+        if not (torch.is_tensor(t) and t.is_cuda and t.device == self._dev()):
+            raise _lib.UcdirError(f"{name} must be a CUDA tensor on {self._dev()} (got "
+                                  f"{t.device if torch.is_tensor(t) else type(t).__name__}); there is no CPU path")
 
     def prepare_guide(self, guide, pad_mode=1):
         L = _lib.load()
         self._sync_weights()
+        self._check_dev("guide", guide)
         key = (guide.data_ptr(), guide._version, tuple(guide.shape), tuple(guide.stride()), pad_mode)
         if key != self._gkey:
             g = guide.contiguous().float()
             B, _, H, W = g.shape
-            _lib.check(L.ucdir_prepare_guide(self._handle(), _ptr(g), B, H, W, pad_mode, _stream_ptr()))
+            _lib.check(L.ucdir_prepare_guide(self._handle(), _ptr(g), B, H, W, pad_mode, _stream_ptr(self._dev())))
             self._gkey = key
             self._guide_keepalive = (guide, g)
 
-    def forward_split(self, cond, x_t, noise_level, guide, pad_mode=1):
-        """eps for cat[cond, x_t] without materialising the concat (model/diffusion.py:166)."""
+    def forward_split(self, cond, x_t, noise_level, guide, pad_mode=1, out=None):
+        """eps for cat[cond, x_t] without materialising the concat (model/diffusion.py:166).
+        ``out``: optional persistent (B,3,H,W) fp32 buffer for eps (graph replay needs stable pointers)."""
         L = _lib.load()
+        for n, t in (("cond", cond), ("x_t", x_t), ("noise_level", noise_level), ("guide", guide)):
+            self._check_dev(n, t)
+        if cond.dim() != 4 or cond.shape != x_t.shape or cond.shape[1] != 3:
+            raise ValueError(f"cond {tuple(cond.shape)} and x_t {tuple(x_t.shape)} must both be (B,3,H,W)")
+        if tuple(guide.shape) != tuple(cond.shape):
+            raise ValueError(f"guide {tuple(guide.shape)} must match cond {tuple(cond.shape)}")
         self.prepare_guide(guide, pad_mode)
         cond = cond.contiguous().float()
         x_t = x_t.contiguous().float()
         lvl = noise_level.reshape(-1).contiguous().float()
         if lvl.numel() != cond.shape[0]:
             raise ValueError("noise_level must have one entry per sample")
-        eps = torch.empty_like(x_t)
         B, _, H, W = x_t.shape
+        if out is not None:
+            if not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.shape == x_t.shape
+                    and out.device == x_t.device):
+                raise ValueError("out must be a contiguous fp32 CUDA tensor shaped like x_t")
+            eps = out
+        else:
+            eps = torch.empty_like(x_t)
         self._last_shape = (B, (H // 32 + 1) * 32, (W // 32 + 1) * 32) if pad_mode else (B, H, W)
-        _lib.check(L.ucdir_unet_forward(self._handle(), _ptr(cond), _ptr(x_t), _ptr(lvl), _ptr(eps), _stream_ptr()))
+        _lib.check(L.ucdir_unet_forward(self._handle(), _ptr(cond), _ptr(x_t), _ptr(lvl), _ptr(eps), B, H, W,
+                                        _stream_ptr(self._dev())))
+        self._io_keepalive = (cond, x_t, lvl)
         return eps
 
     def naiveforward(self, x, time, guide):
@@ -156,7 +219,8 @@ class DY3h(nn.Module):
         _, _, h, w = x.shape
         if h * w > self.patch_threshold:
             return patch_forward_guide(x, self.naiveforward, params={"time": time, "guide": guide},
-                                       skip=self.patch_skip, padding=self.patch_padding)
+                                       skip=self.patch_skip, padding=self.patch_padding, group=self.patch_group,
+                                       max_batch=self.patch_max_batch)
         return self.forward_split(x[:, :3], x[:, 3:], time, guide, pad_mode=1)
 
     def debug_read(self, layer, what="out"):
@@ -169,7 +233,7 @@ class DY3h(nn.Module):
                 lvl = Ld.level + (1 if Ld.kind == "down" else (-1 if Ld.kind == "up" else 0))
                 out = torch.empty(B, Ld.cout, Hc >> lvl, Wc >> lvl, device=next(self.parameters()).device)
                 _lib.check(L.ucdir_debug_read(self._handle(), layer.encode(), what.encode(), _ptr(out), out.numel(),
-                                              _stream_ptr()))
+                                              _stream_ptr(self._dev())))
                 return out
         raise KeyError(layer)
 
@@ -189,9 +253,15 @@ def sampler_step_(x_t, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma):
     L = _lib.load()
     if not (x_t.is_cuda and x_t.is_contiguous() and x_t.dtype == torch.float32):
         raise _lib.UcdirError("sampler_step_ needs contiguous fp32 CUDA tensors")
+    if noise is not None and not (noise.is_cuda and noise.is_contiguous() and noise.dtype == torch.float32
+                                  and noise.numel() == x_t.numel()):
+        raise _lib.UcdirError("sampler_step_: noise must be a contiguous fp32 CUDA tensor shaped like x_t")
+    eps = eps.contiguous()
+    if not (eps.is_cuda and eps.dtype == torch.float32 and eps.numel() == x_t.numel()):
+        raise _lib.UcdirError("sampler_step_: eps must be an fp32 CUDA tensor shaped like x_t")
     nz = _ptr(noise) if noise is not None else ctypes.c_void_p(0)
-    _lib.check(L.ucdir_sampler_step(_ptr(x_t), _ptr(eps.contiguous()), nz, x_t.numel(), float(c_recip),
-                                    float(c_recipm1), float(coef1), float(coef2), float(sigma), _stream_ptr()))
+    _lib.check(L.ucdir_sampler_step(_ptr(x_t), _ptr(eps), nz, x_t.numel(), float(c_recip),
+                                    float(c_recipm1), float(coef1), float(coef2), float(sigma), _stream_ptr(x_t.device)))
     return x_t
 
 
@@ -211,7 +281,22 @@ class UNetSeeInDark(nn.Module):
                 nn.init.uniform_(t, -0.05, 0.05)
             _attach(self, name, nn.Parameter(t))
         self._h = None
-        self._wkey = None
+        self._wdirty = True
+
+    def mark_weights_dirty(self):
+        self._wdirty = True
+
+    def _apply(self, fn, *a, **k):
+        self._wdirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._wdirty = True
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._wdirty = True
+        return super()._load_from_state_dict(*a, **k)
 
     def _handle(self):
         L = _lib.load()
@@ -226,8 +311,7 @@ class UNetSeeInDark(nn.Module):
         return self._h
 
     def _sync_weights(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if key == self._wkey:
+        if not self._wdirty and self._h is not None:
             return
         L = _lib.load()
         h = self._handle()
@@ -236,15 +320,17 @@ class UNetSeeInDark(nn.Module):
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
             _lib.check(L.ucdir_predictor_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
         _lib.check(L.ucdir_predictor_finalize(h))
-        self._wkey = key
+        self._wdirty = False
 
     def forward(self, x):
         L = _lib.load()
         self._sync_weights()
+        if not (torch.is_tensor(x) and x.is_cuda and x.device == next(self.parameters()).device):
+            raise _lib.UcdirError("UNetSeeInDark input must be a CUDA tensor on the module's device; there is no CPU path")
         x = x.contiguous().float()
         B, _, H, W = x.shape
         y = torch.empty_like(x)
-        _lib.check(L.ucdir_predictor_forward(self._handle(), _ptr(x), _ptr(y), B, H, W, _stream_ptr()))
+        _lib.check(L.ucdir_predictor_forward(self._handle(), _ptr(x), _ptr(y), B, H, W, _stream_ptr(x.device)))
         return y
 
     def __del__(self):
