@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle (torch / oneDNN) collapses when oversubscribed: on the GPU box's 256 hardware threads one DY3h
+    # forward takes 5.6 s with the default thread count and 1.5 s with 32 (bench.py cpu_baseline measured the same)
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -25,7 +25,7 @@ def bench_name(k):
     if m:
         tm, epi, mode = int(m.group(1)), int(m.group(2)), int(m.group(3))
         return f"cgemm<{tm},akgm>" if epi == 1 else f"cgemm<{tm},std,{MODE[mode]}>"
-    if "akgm_halo_kernel" in k:
+    if "akgm_halo_kernel" in k or "akgm_halo_stage_kernel" in k:
         return "akgm_halo"                          # <true> / <false> instantiations share one bench row
     if "akgm_pre_kernel" in k:
         return "akgm_pre"
@@ -75,6 +75,47 @@ def main():
                 traffic[bn] = tsum[bn][0] / tsum[bn][1]
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     print(json.dumps(traffic, indent=1))
+    sq_summary(src, tag)
+
+
+def sq_summary(src, tag):
+    """Per-kernel SQ counters (separate --pmc passes) -> profiles/<tag>_pmc_sq.csv with derived fractions.
+    SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per
+    SIMD (MI355X_MICROARCH.md); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)."""
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    nl = collections.defaultdict(int)
+    for sub in ("pmc_sq1", "pmc_sq2"):
+        d = os.path.join(src, sub)
+        if not os.path.isdir(d):
+            continue
+        for f in os.listdir(d):
+            if not f.endswith("counter_collection.csv"):
+                continue
+            seen = collections.defaultdict(set)
+            for r in csv.DictReader(open(os.path.join(d, f))):
+                k = r["Kernel_Name"]
+                tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                seen[k].add(r.get("Dispatch_Id", ""))
+            for k, v in seen.items():
+                nl[k] = max(nl[k], len(v))
+    if not tot:
+        return
+    cols = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+            "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+            "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU"]
+    with open(f"profiles/{tag}_pmc_sq.csv", "w") as out:
+        out.write("kernel,launches," + ",".join(c + "_per_launch" for c in cols) +
+                  ",mfma_busy_frac,wave_wait_frac,wave_valu_frac,valu_per_mfma,lds_conflict_frac\n")
+        for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
+            n = max(nl[k], 1)
+            v = {c: tot[k].get(c, 0.0) / n for c in cols}
+            gui = v["GRBM_GUI_ACTIVE"] or float("nan")
+            wc = v["SQ_WAVE_CYCLES"] or float("nan")
+            derived = [v["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), v["SQ_WAIT_ANY"] / wc, v["SQ_ACTIVE_INST_VALU"] / wc,
+                       v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"] if v["SQ_INSTS_MFMA"] else float("nan"),
+                       v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"] if v["SQ_LDS_IDX_ACTIVE"] else float("nan")]
+            out.write(f"\"{k[:90]}\",{n}," + ",".join("%.0f" % v[c] for c in cols) + "," + ",".join("%.4f" % x for x in derived) + "\n")
+    print(open(f"profiles/{tag}_pmc_sq.csv").read()[:3000])
 
 
 if __name__ == "__main__":

@@ -7,11 +7,15 @@
 //     [unit][k16 step j][k half][128 rows][8 bf16]            (20 KB / 36 KB per unit)
 // and DMA'd linearly (1 KB pieces) together with the halo before anything else happens:
 //   cg = 8 : both units of the workgroup (2 x 20 KB) up front; no barrier inside the K loops;
-//   cg = 16: unit 0 up front, unit 1 streams in underneath unit 0's epilogue.
+//   cg = 16: unit 0 up front, unit 1 streams in underneath unit 0's epilogue (instantiated, not dispatched: the ring
+//            kernel of akgm_halo.hip.h measured faster there).
 // A fragments are conflict-free without a swizzle (32 lanes read 32 consecutive 16-byte slots).
-// Epilogue: modulation sum in registers -> fp32 stage (16 floats per pixel, chunk-swizzled; for
-// cg = 8 it aliases the dead weights of unit 0) -> one (pixel, 8 features) item per thread with the
-// residual.
+// Epilogue WITHOUT LDS and WITHOUT barriers: after the modulation sum a lane holds the lower (lane < 32) or upper
+// (lane >= 32) feature pair of each 4-feature group for its two pixels; one v_permlane32_swap per value hands
+// lanes 0-31 all eight features of pixel tp = 0 and lanes 32-63 all eight of pixel tp = 1 (lane L <-> pixel
+// 64 wq + L), i.e. exactly one 16-byte residual load and one 16-byte store per lane.  The fp32 stage, its two
+// barriers per unit and the LDS round trip are gone: after the single barrier that publishes the DMA'd tiles the
+// eight waves of a workgroup never synchronise again (cg = 8).
 #pragma once
 #include "akgm_halo.hip.h"
 
@@ -21,7 +25,6 @@ struct AkPre {
     static constexpr int A_UNIT = NK16 * 4096;                // bytes
     static constexpr int NA = (CG == 8) ? 2 : 1;              // resident units
     static constexpr int OFF_A = HC_HALO_BYTES;
-    static constexpr int STAGE_BYTES = 256 * 16 * 4;          // aliases the first 16 KB of the weight buffer
     static constexpr int OFF_SCAL = OFF_A + NA * A_UNIT;
     static constexpr int OFF_TCS = OFF_SCAL + 128;
     static constexpr int OFF_ATT = OFF_TCS + NA * 9 * 128 * 4; // [256 px][8] modulation weights G * attw
@@ -34,7 +37,6 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
     unsigned char* abuf = smem + L::OFF_A;
-    float* stage = reinterpret_cast<float*>(smem + L::OFF_A);
     float* scal = reinterpret_cast<float*>(smem + L::OFF_SCAL);
     float* tcs = reinterpret_cast<float*>(smem + L::OFF_TCS);          // [NA][9][128]
     float* attl = reinterpret_cast<float*>(smem + L::OFF_ATT);
@@ -60,6 +62,11 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
     const int nslots = th * tw;
     const float inv_hw = 1.0f / (float)hw, inv_tw = 1.0f / (float)tw;
     const int unit0 = 2 * sec;                                  // first of this workgroup's two units
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
+    int dbg_n = 0;
+#endif
+    AH_STAMP();                                                 // kernel entry
 
     // ---- everything the workgroup needs up front goes into flight now ---------------------------------
     {
@@ -102,13 +109,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
     issue_Tc(unit0 * 16, tcs);
     if (CG == 8) issue_Tc(unit0 * 16 + 16, tcs + 9 * 128);
 
-    float rstd;
-    {
-        float mean_unused;
-        double S, Q;
-        stat_read(p.stats, nullptr, b, S, Q);
-        mean_rstd(S, Q, p.inv_count, mean_unused, rstd);
-    }
+    const float rstd = p.ms[2 * b + 1];
     // ---- per-lane pixel constants (K loop / phase 1) ---------------------------------------------------
     int hp0[2], cls[2];                                                // cls: border class, or -1 for a pixel outside the image / tile
 #pragma unroll
@@ -131,20 +132,20 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
             *reinterpret_cast<float4*>(ap + 4) = make_float4(g1.x * aw[4], g1.y * aw[5], g1.z * aw[6], g1.w * aw[7]);
         }
     }
-    // ---- per-thread item of phase 2: pixel tid>>1, features 8*(tid&1) .. +7 of the unit ---------------
-    const int px2 = tid >> 1, half2 = tid & 1;
+    // ---- store item of this lane: pixel 64 wq + lane, features 8 wm .. 8 wm + 7 of the unit ----------------
     int off2;                                                          // element offset inside the sample, -1 = nothing to store
     {
+        const int px2 = wq * 64 + lane;
         const int r = fdiv_small(px2, inv_tw), c = px2 - r * tw;
         const int y = y0 + r, x = x0 + c;
-        off2 = (px2 < nslots && y < p.H && x < p.W) ? ((y + 1) * p.Wp + (x + 1)) * p.C + half2 * 8 : -1;
+        off2 = (px2 < nslots && y < p.H && x < p.W) ? ((y + 1) * p.Wp + (x + 1)) * p.C + wm * 8 : -1;
     }
     const int a_lane = (hh * 128 + wm * 64 + (lane & 31)) * 16;        // + j*4096 + tm*512
+    // the residual (HBM, 16 bytes per lane and unit) is requested a phase EARLY: unit 0's under the weight / halo DMA,
+    // unit 1's under unit 0's epilogue.  Loaded where it is used, its full HBM latency sat on every unit's critical path.
+    const bf16_t* resp = p.res + (long long)b * p.res_bstride + (off2 >= 0 ? off2 : 0) + unit0 * 16;
+    uint4 rv_cur = off2 >= 0 ? *reinterpret_cast<const uint4*>(resp) : make_uint4(0, 0, 0, 0);
 
-#ifdef UCDIR_TIMING
-    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
-    int dbg_n = 0;
-#endif
     AH_STAMP();
     HC_WAIT(0);
     AH_STAMP();
@@ -214,55 +215,60 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
         __builtin_amdgcn_s_setprio(0);
         AH_STAMP();
 
-        __syncthreads();          // weights of this unit are dead; the previous unit's phase 2 is done with the stage
-        AH_STAMP();
-        if (CG == 16 && u == 0) issue_A(unit0 + 1, 16, 36);          // the part of unit 1's weights the stage does not alias
-        // ---- phase 1: modulation sum in registers -> stage[px][16 features] ---------------------------
+        uint4 rv_next = make_uint4(0, 0, 0, 0);
+        if (u == 0 && off2 >= 0) rv_next = *reinterpret_cast<const uint4*>(resp + 16);
+        if (CG == 16 && u == 0) {            // unit 1's weights / fold table replace unit 0's: every wave is done reading them
+            __syncthreads();
+            issue_A(unit0 + 1, 0, 36);
+            issue_Tc(fbase + 16, tcs);
+        }
+        // ---- modulation sum in registers: vq[tm][q][tp] = feature 8 wm + 4 tm + 2 hh + q of pixel tp (pack_akgm_pre) --
+        float vq[2][2][2];
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
             const int px = wq * 64 + tp * 32 + (lane & 31);
-            const int gsw = (px >> 2) & 3;
             float att[8];
             {
                 const float4 a0 = *reinterpret_cast<const float4*>(attl + px * 8), a1 = *reinterpret_cast<const float4*>(attl + px * 8 + 4);
                 att[0] = a0.x; att[1] = a0.y; att[2] = a0.z; att[3] = a0.w; att[4] = a1.x; att[5] = a1.y; att[6] = a1.z; att[7] = a1.w;
             }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int t32 = wm * 2 + tm;
-                float v[2];
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     float sa = 0.f;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) sa += att[s] * acc[tm][tp][8 * q + s];
-                    v[q] = cls[tp] >= 0 ? rstd * sa : 0.f;
+                    vq[tm][q][tp] = rstd * sa;
                 }
-                *reinterpret_cast<float2*>(&stage[px * 16 + ((t32 ^ gsw) << 2) + 2 * hh]) = make_float2(v[0], v[1]);
-            }
         }
         AH_STAMP();
-        __syncthreads();
-        AH_STAMP();
-        if (CG == 16 && u == 0) issue_Tc(fbase + 16, tcs);
-        // ---- phase 2: swish + residual + statistics + store, 16 bytes per thread ------------------------
+        // ---- half-wave exchange: lanes 0-31 keep pixel tp = 0 and receive its features 4 tm + 2 + q from lanes 32-63, which
+        // keep pixel tp = 1 and receive its features 4 tm + q -----------------------------------------------------------
+        float o8[8];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float lo = vq[tm][q][0], hi = vq[tm][q][1];
+                permlane32_swap(lo, hi);
+                o8[4 * tm + q] = lo;                    // features 4 t32 + {0, 1} (q) come from lanes 0-31, ...
+                o8[4 * tm + 2 + q] = hi;                // ... features 4 t32 + 2 + {0, 1} from lanes 32-63
+            }
+        // ---- swish + residual + statistics + store, 16 bytes per lane -------------------------------------------------
         if (off2 >= 0) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + off2 + fbase);
-            const int gsw = (px2 >> 2) & 3;
-            const float4 a = *reinterpret_cast<const float4*>(&stage[px2 * 16 + (((2 * half2) ^ gsw) << 2)]);
-            const float4 d = *reinterpret_cast<const float4*>(&stage[px2 * 16 + (((2 * half2 + 1) ^ gsw) << 2)]);
-            const float v0[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
-            const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
+            const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv_cur);
             float vv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                vv[i] = silu_fast(v0[i]) + bf2f(rh[i]);
+                vv[i] = silu_fast(o8[i]) + bf2f(rh[i]);
                 s1 += vv[i]; s2 += vv[i] * vv[i];
             }
             *reinterpret_cast<uint4*>(p.out + (long long)b * p.out_bstride + off2 + fbase) = pack8_bf16(vv);
         }
         AH_STAMP();
-        if (CG == 16 && u == 0) { __syncthreads(); issue_A(unit0 + 1, 0, 16); HC_WAIT(0); __syncthreads(); }
+        rv_cur = rv_next;
+        if (CG == 16 && u == 0) { HC_WAIT(0); __syncthreads(); }
     }
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;

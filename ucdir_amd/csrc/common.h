@@ -21,11 +21,15 @@ __host__ __device__ inline float bf2f(bf16_t h) {
     return v.f;
 }
 
-// two fp32 -> packed bf16x2 in one instruction (round-to-nearest-even, same result as f2bf)
+// two fp32 -> packed bf16x2 in one instruction (v_cvt_pk_bf16_f32: round-to-nearest-even, same result as f2bf).
+// Written as native casts, NOT inline asm: hipcc selects the same instruction, and it also pads the hazards around it -
+// an asm statement that reads the result of a transcendental (v_exp_f32 in the flash-attention softmax) with no
+// instruction in between got a stale operand (gfx950 TRANS -> VALU use needs one wait state; nothing inside or in front
+// of an asm statement is padded, cdna guide §5.7).  Found by test_attention at C = 128.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    bf16x2_t v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ uint4 pack8_bf16(const float* v) {
     return make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
@@ -38,6 +42,14 @@ __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
 }
 __device__ __forceinline__ uint4 pack8_f16(const float* v) {
     return make_uint4(pack2_f16(v[0], v[1]), pack2_f16(v[2], v[3]), pack2_f16(v[4], v[5]), pack2_f16(v[6], v[7]));
+}
+
+// v_permlane32_swap_b32: lanes 32-63 of `a` swap with lanes 0-31 of `b` (the other two halves stay).  Inline asm on
+// purpose: with hipcc 7.2 the builtin (__builtin_amdgcn_permlane32_swap) loses its SECOND result when several swaps feed
+// an array - the generated code reuses result 0 for both (reproduced standalone: four swaps, eight stores, registers
+// v1/v3 stored twice, v2/v4 never).  The two wait states a VALU write -> permlane read needs are inside the string.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 __device__ inline float silu_f(float v) { return v / (1.0f + __expf(-v)); }

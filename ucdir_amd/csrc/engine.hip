@@ -122,7 +122,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
-    if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
+    if (P.cg == 8) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
     return W;
 }
 
@@ -167,7 +167,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv3x3_halo_kernel<128, false>, hc_lds_bytes<128>());
     set_lds_attr(conv3x3_halo_kernel<64, false>, hc_lds_bytes<64>());
     set_lds_attr(conv3x3_halo_kernel<64, true>, hc_lds_bytes<64>());
-    set_lds_attr(akgm_halo_kernel<false>, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
+    set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS); set_lds_attr(akgm_pre_kernel<16>, AkPre<16>::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
@@ -370,23 +370,26 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
 }
 
 // halo-tile AKGM kernel (akgm_halo.hip.h): 8 / 16 / 32 / 64 channels per group
-// tcbuf: caller-owned fold-table scratch of at least y.B * 9 * 8 * C floats (the context plans one; nothing is
+// tcbuf: caller-owned fold-table scratch of at least y.B * (9 * 8 * C + 2) floats (the context plans one; nothing is
 // allocated on the launch path, so a forward can be captured into a HIP graph)
 static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const float* attw, const Act& res, Act& y, float* tcbuf, hipStream_t st) {
-    // resident-weights kernel: on by default for 8 channels per group (288^2 level, -5 % vs the ring kernel in same-box
-    // A/B); for 16 per group it measured +7 % slower (exposed reload of unit 1), so it stays opt-in (UCDIR_PRE16)
-    static const bool use_pre = !getenv("UCDIR_NO_PRE"), use_pre16 = getenv("UCDIR_PRE16") != nullptr;
-    const bool pre = use_pre && w.Apre != nullptr && (w.cg == 8 || use_pre16);
+    // resident-weights kernel for 8 channels per group (the 288^2 level); UCDIR_NO_PRE falls back to the ring kernel.
+    // (A persistent variant - one workgroup walking a range of tiles with the weights loaded once - was built and measured
+    // in round 2: 128 registers per wave do not hold the tile-loop state next to 64 accumulators, hipcc spilled 14-39
+    // registers with scratch reloads inside the loop, and the launch went from 238 to 306 us.  See DESIGN.md.)
+    static const bool use_pre = !getenv("UCDIR_NO_PRE");
+    const bool pre = use_pre && w.Apre != nullptr && w.cg == 8;
     require(tcbuf != nullptr, "AKGM: no fold-table scratch");
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
-    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf);
+    float* msbuf = tcbuf + (size_t)y.B * 9 * 8 * w.C;                    // (mean, rstd) per sample, behind the table
+    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
     AkgmHP p;
     p.A = pre ? w.Apre : w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
     p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
     choose_tile(y.H, y.W, p.th, p.tw);
     p.tiles_x = (y.W + p.tw - 1) / p.tw; p.tiles_y = (y.H + p.th - 1) / p.th; p.nbatch = y.B;
     p.stats = h1.stats; p.inv_count = 1.0 / ((double)w.C * h1.H * h1.W);
-    p.Tc = tcbuf;
+    p.Tc = tcbuf; p.ms = msbuf;
     p.G = G; p.g_bstride = (long long)y.H * y.W * 8; p.attw = attw;
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
     const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
@@ -396,10 +399,10 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     static const bool use_attlds = !getenv("UCDIR_NO_ATTLDS");
     const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
     auto launch = [&]() {
-        if (pre && w.cg == 8) hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
-        else if (pre) hipLaunchKernelGGL(akgm_pre_kernel<16>, dim3(nblk), dim3(HC_THREADS), AkPre<16>::LDS, st, p);
-        else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
-        else hipLaunchKernelGGL(akgm_halo_kernel<false>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        if (pre) {
+            hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
+        } else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
+        else hipLaunchKernelGGL(akgm_halo_stage_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
     };
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
@@ -699,6 +702,7 @@ struct ucdir_ctx {
     float* attw = nullptr;              // [nblocks][B][8]
     float* tcbuf = nullptr;             // AKGM fold-table scratch [B][9][8 * max C] (akgm_tc_kernel)
     bool guide_ready = false;
+    bool acts_reused = false;           // plan_shapes recycled activation buffers by lifetime: no debug_read
     double flops = 0;
     // HIP-graph replay of one forward (B = 1 / -p val latency path): captured once per (cond, x_t, level, eps) pointer
     // set on a library-owned stream, replayed on the caller's stream.  Dropped whenever weights or shapes change.
@@ -833,6 +837,28 @@ static void finalize_weights(ucdir_ctx* c) {
 
 static int level_dim(int d, int level) { return d >> level; }
 
+// Activation buffers of one planned shape.  Small shapes (the 256^2 / 416^2 batches) give every tensor its own buffer:
+// 288 GB of HBM makes their few GB irrelevant and ucdir_debug_read can look at any layer after a forward.  Large
+// shapes (the 1024^2 windows of the inter-step patch split: 4.8 GB per window without reuse, six to twenty-four
+// windows per step) recycle buffers by LIFETIME among tensors of IDENTICAL shape: same (H, W, C) means the same
+// zero-bordered layout, so the border a previous tenant left is the zero border the next one needs (kernels never write
+// border cells), and no re-zeroing pass is needed.  A tensor is released after its last reader in launch order:
+// block internals (h1, res, bo) with their block, a layer input when the layer is done unless it sits on the skip
+// stack, a skip when the up block that pops it is done.
+struct ActPlanner {
+    DevPool& pool; int B; bool reuse;
+    std::map<std::array<int, 3>, std::vector<bf16_t*>> free_;
+    Act get(int h, int w, int C, bool stats = true) {
+        Act a; a.B = B; a.H = h; a.W = w; a.C = C;
+        auto& fl = free_[{h, w, C}];
+        if (reuse && !fl.empty()) { a.p = fl.back(); fl.pop_back(); }
+        else a.p = (bf16_t*)pool.alloc((size_t)a.elems() * sizeof(bf16_t), true);
+        if (stats) a.stats = pool.alloc_stats(B);        // statistics are per logical tensor, never shared
+        return a;
+    }
+    void put(const Act& a) { if (reuse && a.p) free_[{a.H, a.W, a.C}].push_back(a.p); }
+};
+
 static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     c->apool.release();
     c->rt.assign(c->layers.size(), LayerRT());
@@ -841,31 +867,36 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     else { c->Hc = H; c->Wc = W; }
     const int nlev = c->cfg.n_mults;
     require(c->Hc % (1 << (nlev - 1)) == 0 && c->Wc % (1 << (nlev - 1)) == 0, "compute size must be divisible by 2^(levels-1)");
+    static const bool keep_env = getenv("UCDIR_KEEP_ACTS") != nullptr;
+    c->acts_reused = !keep_env && (long long)c->Hc * c->Wc > 512LL * 512;
+    ActPlanner ap{c->apool, B, c->acts_reused, {}};
     int maxN = 0, attC = 0;
     double fl = 0;
-    int level = 0;
+    std::vector<size_t> skips;                   // layer indices whose output sits on the skip stack
+    std::vector<bool> is_skip(c->layers.size(), false);
+    long cur = -1;
     for (size_t li = 0; li < c->layers.size(); ++li) {
         const LayerDesc& d = c->layers[li];
         LayerRT& r = c->rt[li];
+        long x1 = -1;
         if (d.kind == "stem") {
-            r.out = make_act(c->apool, B, c->Hc, c->Wc, d.cout);
+            r.out = ap.get(c->Hc, c->Wc, d.cout);
             fl += 2.0 * 9 * d.cin * d.cout * c->Hc * c->Wc;
         } else if (d.kind == "down") {
             const int h = level_dim(c->Hc, d.level + 1), w = level_dim(c->Wc, d.level + 1);
-            r.out = make_act(c->apool, B, h, w, d.cout);
+            r.out = ap.get(h, w, d.cout);
             fl += 2.0 * 9 * d.cin * d.cout * h * w;
-            level = d.level + 1;
         } else if (d.kind == "up") {
             const int h = level_dim(c->Hc, d.level - 1), w = level_dim(c->Wc, d.level - 1);
-            r.out = make_act(c->apool, B, h, w, d.cout);
+            r.out = ap.get(h, w, d.cout);
             fl += 2.0 * 9 * d.cin * d.cout * h * w;
-            level = d.level - 1;
         } else {
             const int h = level_dim(c->Hc, d.level), w = level_dim(c->Wc, d.level);
-            r.h1 = make_act(c->apool, B, h, w, d.cout);
-            if (d.cin != d.cout) r.res = make_act(c->apool, B, h, w, d.cout, false);
-            r.out = make_act(c->apool, B, h, w, d.cout);
-            if (d.attn) r.bo = make_act(c->apool, B, h, w, d.cout);
+            if (d.skip_c) { require(!skips.empty(), "skip stack underflow"); x1 = (long)skips.back(); skips.pop_back(); }
+            r.h1 = ap.get(h, w, d.cout);
+            if (d.cin != d.cout) r.res = ap.get(h, w, d.cout, false);
+            r.out = ap.get(h, w, d.cout);
+            if (d.attn) r.bo = ap.get(h, w, d.cout);
             r.G = (float*)c->apool.alloc((size_t)B * h * w * 8 * sizeof(float));
             const double hw = (double)h * w;
             fl += 2.0 * 9 * d.cin * d.cout * hw + 2.0 * 9 * d.cout * d.cout * hw;
@@ -876,18 +907,24 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
                 attC = d.cout;
                 fl += 2.0 * d.cout * 3 * d.cout * hw + 2.0 * d.cout * d.cout * hw + 4.0 * hw * hw * d.cout;
             }
+            ap.put(r.h1); ap.put(r.res); ap.put(r.bo);          // dead once the block's last launch has been issued
         }
+        if (x1 >= 0) ap.put(c->rt[x1].out);                       // popped skip: consumed by this block
+        if (cur >= 0 && !is_skip[cur]) ap.put(c->rt[cur].out);    // layer input, unless an up block still needs it
+        cur = (long)li;
+        if (d.push_skip) { skips.push_back(li); is_skip[li] = true; }
     }
-    (void)level;
     fl += 2.0 * 9 * c->cfg.inner_channel * c->cfg.channel_mults[0] * c->cfg.out_channel * c->Hc * c->Wc;
     c->flops = fl * B;
-    c->fin_act = make_act(c->apool, B, c->Hc, c->Wc, c->cfg.inner_channel * c->cfg.channel_mults[0], false);
+    c->fin_act = Act();
+    static const bool unfused_final = getenv("UCDIR_NO_FUSED_FINAL") != nullptr;
+    if (!c->fin_w || unfused_final) c->fin_act = make_act(c->apool, B, c->Hc, c->Wc, c->cfg.inner_channel * c->cfg.channel_mults[0], false);
     if (maxN > 0) alloc_attn(c->apool, c->attn, B, maxN, attC, c->cfg.attn_fp16 != 0);
     c->attw = (float*)c->apool.alloc((size_t)c->nblocks * B * 8 * sizeof(float));
     {
         int maxC = 0;
         for (const auto& d : c->layers) if (d.kind == "block" && d.cout > maxC) maxC = d.cout;
-        c->tcbuf = (float*)c->apool.alloc((size_t)B * 9 * 8 * maxC * sizeof(float), false);
+        c->tcbuf = (float*)c->apool.alloc((size_t)B * (9 * 8 * maxC + 2) * sizeof(float), false);
     }
     c->guide_ready = false;
 }
@@ -1105,6 +1142,8 @@ int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, fl
     API_BEGIN
     require(ctx && layer && what && dst, "null argument");
     DevGuard dg(ctx->cfg.device);
+    require(!ctx->acts_reused, "ucdir_debug_read: activation buffers of this (large) shape are recycled by lifetime; set "
+                               "UCDIR_KEEP_ACTS=1 before planning to keep every layer's tensor");
     for (size_t li = 0; li < ctx->layers.size(); ++li) {
         if (ctx->layers[li].name != layer) continue;
         const LayerRT& r = ctx->rt[li];
@@ -1223,7 +1262,7 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_
     std::vector<float> ones((size_t)B * 8, 1.f);
     float* attw = pool.upload(ones);
     AkgmW w = upload_akgm(pool, wsp_host, bsp_host, gamma_host, beta_host, C);
-    float* tcbuf = (float*)pool.alloc((size_t)B * 9 * 8 * C * sizeof(float), false);
+    float* tcbuf = (float*)pool.alloc((size_t)B * (9 * 8 * C + 2) * sizeof(float), false);
     run_akgm(w, ah, G, attw, ar, out, tcbuf, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
     HIPC(hipGetLastError());
