@@ -4,7 +4,7 @@ Every function returns a dict of error metrics; thresholds live in the tests.
 Tolerances (stated once): the HIP path computes convolutions / attention with bf16 operands and
 fp32 accumulation and stores activations in bf16, so vs the fp32 oracle we expect
   * single operator on bf16-representable inputs : rel-RMS <~ 3e-3 (weight + output rounding)
-  * full 61-GroupNorm-deep forward               : rel-RMS <~ 1.5e-2 (measured by emulation), bound 2.5e-2
+  * full 61-GroupNorm-deep forward               : rel-RMS 1.0-1.3e-2 measured (1.44e-2 predicted by emulation), bound 1.5e-2
 """
 import ctypes
 import math

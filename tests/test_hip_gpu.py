@@ -17,7 +17,11 @@ SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn
 SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, attn_res=(16,), image_size=128)
 
 OP_TOL = 4e-3        # single operator, bf16-representable inputs
-FWD_TOL = 2.5e-2     # full forward (61 GroupNorms deep), measured ~1.1-1.5e-2
+FWD_TOL = 1.5e-2     # full forward (61 GroupNorms deep, bf16 operands AND bf16-stored activations): measured 1.1e-2 on the
+                     # full SID configuration, 1.0-1.3e-2 on the small one; SURVEY.md §8c proposed 1e-2 for bf16 operands
+                     # with fp32 activations - storing activations in bf16 is what the extra 0.1-0.3e-2 buys back in HBM traffic
+CROP_TOL = 2.0e-2    # a 3 x 32 x 32 crop of the same forward against the REFERENCE's own output: 3,072 values instead of
+                     # 196,608, the estimate of the same error is noisier
 
 
 @pytest.fixture(scope="module")
@@ -75,6 +79,8 @@ def test_forward_small_vs_oracle_and_golden(golden_dir):
         assert not m["nan"] and m["rel_rms"] < FWD_TOL, (k, m)
     g = np.load(os.path.join(golden_dir, "small_forward.npz"))       # output of the real reference
     gm = C.metrics(eps, torch.from_numpy(g["eps"].astype(np.float32)))
+    print("SMALL forward vs oracle:", out["eps"], " vs reference golden:", gm, " worst layer:",
+          max((m["rel_rms"], k) for k, m in out.items()))
     assert gm["rel_rms"] < FWD_TOL, gm
 
 
@@ -84,7 +90,8 @@ def test_forward_sid_full_config(golden_dir, sid_net):
     g = np.load(os.path.join(golden_dir, "sid_forward.npz"))         # crops of the real reference's output
     crop = eps[0, :, 100:132, 60:92]
     gm = C.metrics(crop, torch.from_numpy(g["eps1_crop"]))
-    assert gm["rel_rms"] < 2 * FWD_TOL, gm
+    print("full SID forward vs oracle:", out["eps"], " crop vs reference golden:", gm)
+    assert gm["rel_rms"] < CROP_TOL, gm
 
 
 def test_forward_batch_is_independent(sid_net):
@@ -296,5 +303,5 @@ def test_alternative_kernel_paths_agree():
         assert "FAILED" not in line, line
         out[tag] = json.loads(line[line.index("{"):])
     for tag, m in out.items():
-        assert not m["eps"]["nan"] and m["eps"]["rel_rms"] < 2.5e-2, (tag, m["eps"])
+        assert not m["eps"]["nan"] and m["eps"]["rel_rms"] < FWD_TOL, (tag, m["eps"])
     assert abs(out["default"]["eps"]["rel_rms"] - out["plain"]["eps"]["rel_rms"]) < 5e-3, (out["default"]["eps"], out["plain"]["eps"])

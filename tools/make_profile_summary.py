@@ -81,7 +81,9 @@ def main():
 def sq_summary(src, tag):
     """Per-kernel SQ counters (separate --pmc passes) -> profiles/<tag>_pmc_sq.csv with derived fractions.
     SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per
-    SIMD (MI355X_MICROARCH.md); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)."""
+    SIMD (= 32 x the number of 32x32x16 MFMAs, MI355X_MICROARCH.md; checked: 150.8M = 32 x 4.712M for conv3x3_halo<128>).
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs (2.97M per 183 us launch = 8 x 371k cycles = 2.03 GHz), so
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)."""
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     nl = collections.defaultdict(int)
     for sub in ("pmc_sq1", "pmc_sq2"):
@@ -105,13 +107,13 @@ def sq_summary(src, tag):
             "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU"]
     with open(f"profiles/{tag}_pmc_sq.csv", "w") as out:
         out.write("kernel,launches," + ",".join(c + "_per_launch" for c in cols) +
-                  ",mfma_busy_frac,wave_wait_frac,wave_valu_frac,valu_per_mfma,lds_conflict_frac\n")
+                  ",mfma_busy_frac,wave_wait_frac,wave_valu_frac,valu_per_mfma,lds_conflict_frac,clock_ghz_x_us\n")
         for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
             n = max(nl[k], 1)
             v = {c: tot[k].get(c, 0.0) / n for c in cols}
             gui = v["GRBM_GUI_ACTIVE"] or float("nan")
             wc = v["SQ_WAVE_CYCLES"] or float("nan")
-            derived = [v["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), v["SQ_WAIT_ANY"] / wc, v["SQ_ACTIVE_INST_VALU"] / wc,
+            derived = [v["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024), v["SQ_WAIT_ANY"] / wc, v["SQ_ACTIVE_INST_VALU"] / wc,
                        v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"] if v["SQ_INSTS_MFMA"] else float("nan"),
                        v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"] if v["SQ_LDS_IDX_ACTIVE"] else float("nan")]
             out.write(f"\"{k[:90]}\",{n}," + ",".join("%.0f" % v[c] for c in cols) + "," + ",".join("%.4f" % x for x in derived) + "\n")
