@@ -39,6 +39,10 @@ def sid_net():
     (1, 16, 24, 64, 0, 64, 3, 2, False, False, False),
     (2, 24, 40, 128, 64, 64, 1, 0, False, False, True),    # res_conv 1x1 + residual
     (1, 12, 12, 512, 0, 512, 1, 0, True, False, False),    # qkv-like 1x1 with GN fold
+    (1, 18, 18, 512, 512, 512, 3, 0, True, True, False),   # split-K: 16 workgroups x 32 chunks (the B = 1 latency path)
+    (1, 36, 36, 256, 0, 512, 3, 0, True, True, True),      # split-K with a residual
+    (1, 18, 18, 512, 0, 512, 3, 2, False, False, False),   # split-K Upsample parity launches
+    (3, 18, 18, 512, 256, 512, 3, 0, True, True, False),   # split-K, ragged chunk ranges (24 chunks over 5 splits)
 ])
 def test_conv_gemm(args):
     m = C.conv_case(*args)
@@ -100,10 +104,21 @@ def test_forward_batch_is_independent(sid_net):
     from ucdir_amd.weights import synth_inputs
     cond, guide, x_t = map(torch.from_numpy, synth_inputs(3, 96, 64, seed=3))
     lvl = torch.tensor([[0.1], [0.5], [0.9]])
-    with torch.no_grad():
-        full = net.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda()).cpu()
-        one = net.denoise_fn(torch.cat([cond[1:2], x_t[1:2]], 1).cuda(), lvl[1:2].cuda(), guide[1:2].cuda()).cpu()
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"splitk", 0))       # split-K depends on the grid size, i.e. on B: another summation order
+    try:
+        with torch.no_grad():
+            full = net.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda()).cpu()
+            one = net.denoise_fn(torch.cat([cond[1:2], x_t[1:2]], 1).cuda(), lvl[1:2].cuda(), guide[1:2].cuda()).cpu()
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"splitk", -1))
     assert torch.equal(full[1:2], one)          # bit exact: same tiles, same reduction order
+    with torch.no_grad():                       # default launch configuration (split-K for the single sample's small grids)
+        one_s = net.denoise_fn(torch.cat([cond[1:2], x_t[1:2]], 1).cuda(), lvl[1:2].cuda(), guide[1:2].cuda()).cpu()
+        one_s2 = net.denoise_fn(torch.cat([cond[1:2], x_t[1:2]], 1).cuda(), lvl[1:2].cuda(), guide[1:2].cuda()).cpu()
+    assert torch.equal(one_s, one_s2)           # partial tiles are summed in a fixed order: reproducible
+    m = C.metrics(one_s, one)
+    assert m["rel_rms"] < FWD_TOL, m
 
 
 def test_forward_bit_reproducible_at_bench_size(sid_net):
@@ -137,7 +152,8 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
     (2, 288, 288, 64, 64, 3, 0, 1),       # conv3x3_halo<64> with the GroupNorm fold
     (2, 144, 144, 128, 128, 3, 0, 1),     # conv3x3_halo<128>
     (2, 72, 72, 256, 256, 3, 2, 0),       # Upsample parity launches
-], ids=["1x1_64", "down_64", "halo_64", "halo_128", "up_256"])
+    (1, 18, 18, 1024, 512, 3, 0, 1),      # split-K: partial tiles summed in a fixed order by conv_splitk_finish_kernel
+], ids=["1x1_64", "down_64", "halo_64", "halo_128", "up_256", "splitk"])
 def test_output_statistics_exact_and_reproducible(args):
     """The (sum, sum of squares) a launch accumulates with fixed-point atomics equal float64 sums of the output it stored
     (up to the bf16 rounding of that output) and are bit-identical from run to run, at the network's real level sizes."""

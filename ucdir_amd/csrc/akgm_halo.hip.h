@@ -26,6 +26,7 @@ struct AkgmHP {
     const bf16_t* res; long long res_bstride;
     bf16_t* out; long long out_bstride;
     stat_t* stats_out;                         // (sum, sum of squares) accumulators of the output (stat_add)
+    int usplit;                                // akgm_halo_stage_kernel, 64 per group: the 4 units of a group go to 1 | 2 | 4 workgroups
     unsigned long long* dbg;
 };
 
@@ -41,17 +42,23 @@ struct AkgmHP {
 __global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_count, const float* __restrict__ bias,
                                const float* __restrict__ Tb, const float* __restrict__ Tg, int n, float* __restrict__ Tc,
                                float* __restrict__ ms) {
-    const int b = blockIdx.y, cls = blockIdx.x;
+    // grid (9 classes x ceil(n / 1024), B), 256 threads, four values per thread (n = 8C is a multiple of 512)
+    const int b = blockIdx.y, cls = blockIdx.x % 9, o = ((blockIdx.x / 9) * 256 + threadIdx.x) * 4;
     float mean, rstd;
     double S, Q;
     stat_read(stats, nullptr, b, S, Q);
     mean_rstd(S, Q, inv_count, mean, rstd);
     // the AKGM workgroups (10,368 per launch at the 288^2 level) read these two floats instead of each of their 512
     // threads summing 32 fixed-point slots and redoing the fp64 mean / variance arithmetic
-    if (cls == 0 && threadIdx.x == 0) { ms[2 * b] = mean; ms[2 * b + 1] = rstd; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ms[2 * b] = mean; ms[2 * b + 1] = rstd; }
+    if (o >= n) return;
     const float inv = 1.0f / rstd;
-    for (int o = threadIdx.x; o < n; o += blockDim.x)
-        Tc[((long long)b * 9 + cls) * n + o] = (bias[o] + Tb[(long long)cls * n + o]) * inv - mean * Tg[(long long)cls * n + o];
+    const float4 bi = *reinterpret_cast<const float4*>(bias + o);
+    const float4 tb = *reinterpret_cast<const float4*>(Tb + (long long)cls * n + o);
+    const float4 tg = *reinterpret_cast<const float4*>(Tg + (long long)cls * n + o);
+    *reinterpret_cast<float4*>(Tc + ((long long)b * 9 + cls) * n + o) =
+        make_float4((bi.x + tb.x) * inv - mean * tg.x, (bi.y + tb.y) * inv - mean * tg.y,
+                    (bi.z + tb.z) * inv - mean * tg.z, (bi.w + tb.w) * inv - mean * tg.w);
 }
 
 // ATT_LDS (16 / 32 channels per group: one halo chunk per workgroup, the second halo buffer is free): the per-pixel
@@ -408,6 +415,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_stage_kernel(const Ak
     }
     const int cg = p.cg;
     const int nsec = (cg == 8) ? p.C / 32 : ((cg == 16) ? 4 : 8);   // work sections per pixel tile: 32-channel chunks or groups
+    // under-filled grids (B = 1, the 18^2 level): the units of a section are spread over usplit workgroups
+    const int usplit = (cg == 64 && p.usplit > 1) ? p.usplit : 1;
+    const int usub = lid % usplit;
+    lid /= usplit;
     const int sec = lid % nsec;
     int tq = lid / nsec;
     const int tx = tq % p.tiles_x; tq /= p.tiles_x;
@@ -418,7 +429,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_stage_kernel(const Ak
     const int hcount = (th + 2) * hw;
     const int nslots = th * tw;
     const float inv_hw = 1.0f / (float)hw, inv_tw = 1.0f / (float)tw;
-    const int nunits = (cg == 64) ? 4 : 2;
+    const int nunits = ((cg == 64) ? 4 : 2) / usplit;
+    const int unit0 = usub * nunits;
     const int nchunks = (cg == 64) ? 2 : 1;                 // halo chunks (32 channels each) this workgroup needs
     const int chunk0 = (cg == 64) ? 2 * sec : sec;
     const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift   (cg >= 16)
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_stage_kernel(const Ak
 #endif
     AH_STAMP();
     float s1 = 0.f, s2 = 0.f;
-    for (int unit = 0; unit < nunits; ++unit) {
+    for (int unit = unit0; unit < unit0 + nunits; ++unit) {
         int group, fbase, base16;
         const bf16_t* Au;
         if (cg == 8) {       // unit = two adjacent groups (64 rows each): row half wm belongs to group 4*sec + 2*unit + wm

@@ -163,5 +163,9 @@ struct GemmP {
     // AKGM
     const float* G; long long g_bstride;   // guide branch, compact [B][H*W][8]
     const float* attw;                      // [B][8]
+    // conv3x3_halo split-K (grids that leave most of the chip idle): ksplit workgroups share a tile, each reduces a range of
+    // channel chunks and writes raw fp32 accumulators to partial [wg][ksplit][256 px][TM]; conv_splitk_finish_kernel sums them
+    // in a FIXED order (bit-reproducible) and runs the epilogue
+    int ksplit; float* partial;
     unsigned long long* dbg;                // UCDIR_TIMING builds: s_memtime stamps of one workgroup
 };

@@ -83,6 +83,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int ksplit = DUAL ? 1 : p.ksplit;                               // (the fused-res_conv variant has no register to spare)
+    int split = 0;
+    if (ksplit > 1) { split = lid % ksplit; lid /= ksplit; }       // the splits of a tile are neighbours (same XCD)
+    const int wgid = lid;
     int par = 0;
     if (p.up_phase) { par = lid & 3; lid >>= 2; }
     const int py = par >> 1, pxp = par & 1;
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     // MFMA stayed at ~14k cycles - the ordinary loads below queue behind the DMA in the in-order VMEM path - and the 64-row
     // launches got 10 % slower.  Kept in this order.)
 
-    {
+    // GroupNorm statistics of the input + fold table of this workgroup's rows (split-K workgroups have no epilogue: no table)
+    auto build_table = [&]() {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
             double S, Q;
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             if (p.fold && f < p.nfeat) v += p.Tb[(long long)cls * p.tab_ld + f] - mr * p.Tg[(long long)cls * p.tab_ld + f];
             tcs[i] = v;
         }
-    }
+    };
+    if (ksplit <= 1) build_table();
 
     // ---- halo loader geometry: instruction k = i*8 + wave stages halo pixels 16k .. 16k+15 ------
     int hsrc[3], hjsw[3];
@@ -137,14 +143,16 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         hsrc[i] = (hp < hcount) ? (gy * p.Wp + gx) : -1;
         hjsw[i] = (lane & 3) ^ ((hp >> 2) & 3);
     }
-    const int nchunks = p.cg / HC_BK;
+    const int nchunks_all = p.cg / HC_BK;
+    const int cbeg = (ksplit > 1) ? split * nchunks_all / ksplit : 0;            // this workgroup's channel chunks
+    const int nchunks = (ksplit > 1) ? (split + 1) * nchunks_all / ksplit : nchunks_all;   // (end of the range)
     const int nh_min = ((hcount + 15) / 16) / 8;    // halo staging instructions every wave issues (some issue one more)
     // DUAL (64-row tiles only): a second accumulator set carries the block's res_conv as a 10th tap
     static_assert(!DUAL || TM == 64, "fused res_conv needs the 64-row tile");
     constexpr bool res_fused = DUAL;
     const int ntap = p.up_phase ? 4 : (res_fused ? 10 : 9);   // tap 9 = the block's 1x1 res_conv on the centre pixel
     const int nsteps_c = (ntap + TPS - 1) / TPS;   // steps per chunk
-    const int nk = nchunks * nsteps_c;
+    const int nk = (nchunks - cbeg) * nsteps_c;
     auto issue_halo = [&](int c, int buf) {
         int ch = c * HC_BK;
         const bf16_t* src; int ld;
@@ -208,9 +216,9 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
 
     HC_STAMP(0);
     // ---- K loop: s = c*9 + t -------------------------------------------------------------------------
-    issue_halo(0, 0);
-    issue_A(0, 0, 0);
-    int c = 0, u = 0;                           // chunk and tap pair of the step being computed
+    issue_halo(cbeg, cbeg & 1);
+    issue_A(cbeg, 0, 0);
+    int c = cbeg, u = 0;                        // chunk and tap pair of the step being computed
     for (int s = 0; s < nk; ++s) {
         // everything older than the halo prefetch issued one step ago must have landed
         if (u == 1 && c + 1 < nchunks) hc_wait_vm(nh_min); else { HC_WAIT(0); }
@@ -272,6 +280,27 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         if (++u == nsteps_c) { u = 0; ++c; }
     }
     HC_STAMP(5);
+
+    if (!DUAL && ksplit > 1) {
+        // split-K: raw fp32 partial sums go to partial [wg][split][px][TM] straight from the accumulator layout (4 consecutive
+        // features per lane); conv_splitk_finish_kernel sums them and runs the epilogue.  (Letting the workgroup that draws
+        // a tile's last ticket do that here was measured: the device-scope release / acquire fences it needs write back and
+        // invalidate the XCD's whole L2 on this chip - ~80 us per launch, B = 1 forward 2.8 -> 4.6 ms.)
+        float* pw = p.partial + ((long long)wgid * ksplit + split) * (256 * TM);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+                const int px = wq * TPW + tp * 32 + (lane & 31);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
+                    *reinterpret_cast<float4*>(&pw[px * TM + f]) =
+                        make_float4(acc[tm][tp][rg * 4 + 0], acc[tm][tp][rg * 4 + 1], acc[tm][tp][rg * 4 + 2], acc[tm][tp][rg * 4 + 3]);
+                }
+            }
+        return;
+    }
 
     // ---- epilogue in passes of PXH pixels ------------------------------------------------------------
     const float rstd_s = scal[1];
@@ -405,5 +434,89 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             for (int w = 0; w < 8; ++w) { t1 += scal[2 + w * 2]; t2s += scal[3 + w * 2]; }
             stat_add(p.stats_out, b, t1, t2s);
         }
+    }
+}
+
+
+// Second half of a split-K conv3x3_halo launch: sums the ksplit partial tiles of every output element in split order (fixed:
+// bit-reproducible) and applies conv3x3_halo_kernel's epilogue: GroupNorm fold, bias, activation, residual, statistics of
+// the output, bf16 NHWC store.  grid = (blocks per sample, B); a thread owns 8 features of one output pixel.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const GemmP p, int TM) {
+    __shared__ float sh[20];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) {
+        float mean = 0.f, rstd = 1.f;
+        if (p.fold) {
+            double S, Q;
+            stat_read(p.stats0, p.stats1, b, S, Q);
+            mean_rstd(S, Q, p.inv_count, mean, rstd);
+        }
+        sh[0] = mean; sh[1] = rstd;
+    }
+    __syncthreads();
+    const float mean = sh[0], rstd = sh[1], mr = mean * rstd;
+    const float alpha = p.alpha * (p.fold ? rstd : 1.0f);
+    const int Ho = p.up_phase ? 2 * p.H : p.H, Wo = p.up_phase ? 2 * p.W : p.W;
+    const int nf8 = p.nfeat / 8;
+    const int items = Ho * Wo * nf8;
+    const long long tile = 256LL * TM;
+    float s1 = 0.f, s2 = 0.f;
+    for (int it = blockIdx.x * 256 + tid; it < items; it += gridDim.x * 256) {
+        const int pix = it / nf8, f = (it - pix * nf8) * 8;
+        const int Y = pix / Wo, X = pix - Y * Wo;
+        int y = Y, x = X, par = 0;
+        if (p.up_phase) { par = (Y & 1) * 2 + (X & 1); y = Y >> 1; x = X >> 1; }
+        const int ty = y / p.th, tx = x / p.tw;
+        const int slot = (y - ty * p.th) * p.tw + (x - tx * p.tw);
+        const int rowtile = f / TM, fl = f - rowtile * TM;
+        long long wg = (((long long)b * p.tiles_y + ty) * p.tiles_x + tx) * p.rowtiles + rowtile;
+        if (p.up_phase) wg = wg * 4 + par;
+        const float* pb = p.partial + wg * p.ksplit * tile + (long long)slot * TM + fl;
+        float4 a = *reinterpret_cast<const float4*>(pb), d = *reinterpret_cast<const float4*>(pb + 4);
+        for (int s = 1; s < p.ksplit; ++s) {
+            const float4 a1 = *reinterpret_cast<const float4*>(pb + s * tile), d1 = *reinterpret_cast<const float4*>(pb + s * tile + 4);
+            a.x += a1.x; a.y += a1.y; a.z += a1.z; a.w += a1.w; d.x += d1.x; d.y += d1.y; d.z += d1.z; d.w += d1.w;
+        }
+        float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + f), b1 = *reinterpret_cast<const float4*>(p.bias + f + 4);
+            t[0] = b0.x; t[1] = b0.y; t[2] = b0.z; t[3] = b0.w; t[4] = b1.x; t[5] = b1.y; t[6] = b1.z; t[7] = b1.w;
+        }
+        if (p.fold) {
+            const int cls = (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+            const float* tb = p.Tb + (long long)cls * p.tab_ld + f;
+            const float* tg = p.Tg + (long long)cls * p.tab_ld + f;
+            const float4 b0 = *reinterpret_cast<const float4*>(tb), b1 = *reinterpret_cast<const float4*>(tb + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(tg), g1 = *reinterpret_cast<const float4*>(tg + 4);
+            t[0] += b0.x - mr * g0.x; t[1] += b0.y - mr * g0.y; t[2] += b0.z - mr * g0.z; t[3] += b0.w - mr * g0.w;
+            t[4] += b1.x - mr * g1.x; t[5] += b1.y - mr * g1.y; t[6] += b1.z - mr * g1.z; t[7] += b1.w - mr * g1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + t[i];
+        if (p.act == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
+        }
+        const long long cp = (long long)(Y + 1) * (Wo + 2) + (X + 1);
+        if (p.res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);
+            const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bf2f(rh[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = pack8_bf16(v);
+    }
+    if (p.stats_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        if ((tid & 63) == 0) { sh[2 + (tid >> 6) * 2] = s1; sh[3 + (tid >> 6) * 2] = s2; }
+        __syncthreads();
+        if (tid == 0) stat_add(p.stats_out, b, sh[2] + sh[4] + sh[6] + sh[8], sh[3] + sh[5] + sh[7] + sh[9]);
     }
 }

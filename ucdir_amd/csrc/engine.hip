@@ -158,6 +158,8 @@ template <int TM> static void set_cgemm_attrs() {
     set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_UP>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_PLAIN>, 100 * 1024);
     set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024);
 }
+#define SPLITK_MAX_WGS 512
+static std::map<int, float*> g_splitk_buf;     // split-K scratch per device (see splitk_scratch)
 static void ensure_kernel_attrs() {
     static std::set<int> done;
     int dev = 0;
@@ -174,6 +176,9 @@ static void ensure_kernel_attrs() {
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
     set_lds_attr(flash_attn_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn_kernel<3, true>, fa_lds_bytes(384));
     set_lds_attr(flash_attn_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn_kernel<4, true>, fa_lds_bytes(512));
+    float* sk = nullptr;
+    HIPC(hipMalloc((void**)&sk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));
+    g_splitk_buf[dev] = sk;
     done.insert(dev);
 }
 
@@ -270,22 +275,56 @@ static void choose_tile(int H, int W, int& th, int& tw) {
 
 template <int TM, bool DUAL = false>
 static void launch_halo(const GemmP& p, hipStream_t st) {
-    const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1) * ks;
+    auto finish = [&]() {
+        if (ks == 1) return;
+        const long long items = (long long)p.H * p.W * (p.up_phase ? 4 : 1) * (p.nfeat / 8);
+        int gx = (int)((items + 255) / 256); if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(gx, p.nbatch), dim3(256), 0, st, p, TM);
+    };
+
     if (g_prof.on) {
         ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0) + (DUAL ? 2 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
         e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
         hipLaunchKernelGGL((conv3x3_halo_kernel<TM, DUAL>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+        finish();
         HIPC(hipEventRecord(e.e1, st));
         g_prof.entries.push_back(e);
     } else {
         hipLaunchKernelGGL((conv3x3_halo_kernel<TM, DUAL>), dim3(nblk), dim3(HC_THREADS), hc_lds_bytes<TM>(), st, p);
+        finish();
     }
     HIPC(hipGetLastError());
 }
 
 static bool g_use_halo = true;
+
+// split-K scratch: raw fp32 partial tiles of at most SPLITK_MAX_WGS workgroups of 256 px x 128 rows (64 MiB), one per device, allocated with the kernel attributes (never on the launch path: forwards are captured into HIP graphs)
+static float* splitk_scratch() {
+    int dev = 0;
+    HIPC(hipGetDevice(&dev));
+    auto it = g_splitk_buf.find(dev);
+    require(it != g_splitk_buf.end(), "split-K scratch not allocated on this device");
+    return it->second;
+}
+// number of K splits for a conv3x3_halo grid of `wgs` workgroups over `nchunks` 32-channel chunks: fill ~2 workgroups per CU,
+// at least two chunks per split.  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
+static int g_splitk = -1;           // -1: environment (UCDIR_SPLITK=0 disables), 0 / 1: ucdir_debug_flag("splitk", v)
+static bool splitk_on() {
+    static const bool env_on = !(getenv("UCDIR_SPLITK") && atoi(getenv("UCDIR_SPLITK")) == 0);
+    return g_splitk < 0 ? env_on : g_splitk != 0;
+}
+static int choose_ksplit(int wgs, int nchunks) {
+    static const int lim = getenv("UCDIR_SPLITK_WGS") ? atoi(getenv("UCDIR_SPLITK_WGS")) : 128;
+    if (!splitk_on() || wgs > lim || wgs <= 0) return 1;
+    int ks = SPLITK_MAX_WGS / wgs;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : ks;
+}
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
 // res_out != nullptr asks for the block's res_conv output from the same launch; returns true if it was produced
@@ -353,6 +392,10 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         p.out2 = res_out->p; p.out2_bstride = res_out->bstride(); p.out2_ld = res_out->C;
         did_res = true;
     }
+    if (halo && !did_res && !p.out_nchw && w.cout % 8 == 0) {
+        const int ks = choose_ksplit(p.nbatch * p.tiles * p.rowtiles, cin / HC_BK);
+        if (ks > 1) { p.ksplit = ks; p.partial = splitk_scratch(); }
+    }
     if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else if (did_res) launch_halo<64, true>(p, st); else launch_halo<64>(p, st); }
     else launch_cgemm(p, w.TM, EPI_STD, st);
 #ifdef UCDIR_TIMING
@@ -382,7 +425,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     require(tcbuf != nullptr, "AKGM: no fold-table scratch");
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
     float* msbuf = tcbuf + (size_t)y.B * 9 * 8 * w.C;                    // (mean, rstd) per sample, behind the table
-    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9, y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
+    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9 * ((8 * w.C + 1023) / 1024), y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
     AkgmHP p;
     p.A = pre ? w.Apre : w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
     p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
@@ -394,7 +437,12 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.res = res.p; p.res_bstride = res.bstride(); p.out = y.p; p.out_bstride = y.bstride();
     const int nsec = (w.cg == 8) ? w.C / 32 : ((w.cg == 16) ? 4 : 8);
     p.stats_out = y.stats;
-    const int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
+    int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
+    p.usplit = 1;
+    if (w.cg == 64 && !pre) {              // grids that leave CUs idle: one workgroup per 2 | 1 of a group's 4 units instead of all 4
+        if (splitk_on()) p.usplit = (nblk * 4 <= SPLITK_MAX_WGS) ? 4 : ((nblk * 2 <= SPLITK_MAX_WGS) ? 2 : 1);
+        nblk *= p.usplit;
+    }
     p.dbg = nullptr;
     static const bool use_attlds = !getenv("UCDIR_NO_ATTLDS");
     const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
@@ -1166,6 +1214,7 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     API_BEGIN
     require(name != nullptr, "null argument");
     if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
+    else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END
 }
