@@ -121,7 +121,9 @@ def akgm_case(B, C, H, W, seed=0):
     return m
 
 
-def attention_case(B, C, H, W, seed=0, fp16=False):
+def attention_case(B, C, H, W, seed=0, fp16=False, flash=1):
+    """flash: 1 forces the flash kernel (the engine's own choice sends grids of < 32 query blocks through the three-launch
+    materialised path), 0 forces the materialised path, -1 leaves the choice to the engine."""
     L = ulib.load()
     g = rng(seed)
     x = bfr(torch.randn(B, C, H, W, generator=g) * 1.2 + 0.3)
@@ -133,10 +135,14 @@ def attention_case(B, C, H, W, seed=0, fp16=False):
     dy = torch.empty(B, C, H, W, device=DEV)
     n = lambda k: sd[k].numpy().copy()
     dx = x.to(DEV)
-    ulib.check(L.ucdir_op_attention(_p(dx), B, C, H, W, _hp(n("a.norm.weight")), _hp(n("a.norm.bias")),
-                                    _hp(n("a.qkv.weight")), _hp(n("a.out.weight")), _hp(n("a.out.bias")), int(fp16),
-                                    _p(dy), _st()))
-    torch.cuda.synchronize()
+    ulib.check(L.ucdir_debug_flag(b"flash", flash))
+    try:
+        ulib.check(L.ucdir_op_attention(_p(dx), B, C, H, W, _hp(n("a.norm.weight")), _hp(n("a.norm.bias")),
+                                        _hp(n("a.qkv.weight")), _hp(n("a.out.weight")), _hp(n("a.out.bias")), int(fp16),
+                                        _p(dy), _st()))
+        torch.cuda.synchronize()
+    finally:
+        ulib.check(L.ucdir_debug_flag(b"flash", -1))
     # the residual dominates y; report the error relative to the attention branch alone
     m = metrics(dy, y)
     branch = y - x

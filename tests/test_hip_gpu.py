@@ -60,8 +60,9 @@ def test_akgm(Cc):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18)])
-def test_attention(shape):
-    m = C.attention_case(*shape)
+@pytest.mark.parametrize("flash", [1, -1], ids=["flash", "engine_choice"])
+def test_attention(shape, flash):
+    m = C.attention_case(*shape, flash=flash)
     assert not m["nan"] and m["rel_rms_branch"] < 1.2e-2, m
 
 
@@ -159,7 +160,9 @@ def test_output_statistics_exact_and_reproducible(args):
     (up to the bf16 rounding of that output) and are bit-identical from run to run, at the network's real level sizes."""
     m = C.conv_stats_case(*args)
     assert m["outputs_reproducible"] and m["stats_reproducible"], m
-    assert m["stats_rel"] < 3e-5, m
+    # the stored output is bf16-rounded AFTER the statistics are taken: the rounding noise averages out as 1/sqrt(elements),
+    # so the 18^2 x 512 tensor of the split-K case (166 k elements against >= 1.3 M) gets a wider bound
+    assert m["stats_rel"] < (1e-4 if args[1] * args[2] < 72 * 72 else 3e-5), m
 
 
 def test_restoration_is_bit_reproducible(sid_net):

@@ -311,17 +311,17 @@ static float* splitk_scratch() {
     return it->second;
 }
 // number of K splits for a conv3x3_halo grid of `wgs` workgroups over `nchunks` 32-channel chunks: fill ~2 workgroups per CU,
-// at least two chunks per split.  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
+// at least three chunks per split.  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
 static int g_splitk = -1;           // -1: environment (UCDIR_SPLITK=0 disables), 0 / 1: ucdir_debug_flag("splitk", v)
 static bool splitk_on() {
     static const bool env_on = !(getenv("UCDIR_SPLITK") && atoi(getenv("UCDIR_SPLITK")) == 0);
     return g_splitk < 0 ? env_on : g_splitk != 0;
 }
 static int choose_ksplit(int wgs, int nchunks) {
-    static const int lim = getenv("UCDIR_SPLITK_WGS") ? atoi(getenv("UCDIR_SPLITK_WGS")) : 128;
+    static const int lim = getenv("UCDIR_SPLITK_WGS") ? atoi(getenv("UCDIR_SPLITK_WGS")) : 256;
     if (!splitk_on() || wgs > lim || wgs <= 0) return 1;
     int ks = SPLITK_MAX_WGS / wgs;
-    if (ks > nchunks / 2) ks = nchunks / 2;
+    if (ks > nchunks / 3) ks = nchunks / 3;             // at least three chunks (7 - 9 K steps) per split
     if (ks > 16) ks = 16;
     return ks < 2 ? 1 : ks;
 }
@@ -532,6 +532,10 @@ static bool flash_ok(int C) {
 static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C, bool half) {
     a.B = B; a.N = N; a.C = C; a.Npad = ((N + 63) / 64) * 64;
     a.half = half; a.flash = flash_ok(C);
+    // a handful of query blocks (B = 1 at the 36^2 / 18^2 levels: 11 / 3 workgroups on 256 CUs, each walking every KV tile
+    // alone) is the one case the three-launch materialised path wins (94 -> ~55 us at N = 1296); its score tensors are
+    // small there by construction.  An explicit ucdir_debug_flag("flash", 1) keeps the flash kernel (tests).
+    if (a.flash && !half && g_flash < 0 && B * ((N + FA_BQ - 1) / FA_BQ) < 32 && N <= 2048) a.flash = false;
     require(a.flash || !half, "fp16 attention operands need the flash kernel (C % 128 == 0, C <= 512)");
     a.qkv = (bf16_t*)pool.alloc((size_t)B * N * 3 * C * 2);
     if (!a.flash) {
