@@ -73,6 +73,52 @@ def cpu_baseline(T, size):
                       f"restatement (oracle/)"}
 
 
+class LaunchProfile:
+    """HIP-event brackets around the GEMM-core launches of selected forwards (library hooks ucdir_profile_*), read back as
+    per-kernel-instantiation totals: the roofline leg, measured inside the timed region."""
+    CAP = 32
+
+    def __init__(self, L, ulib):
+        self.L, self.ulib = L, ulib
+        c = self.CAP
+        self.keys = (ctypes.c_int32 * c)(); self.ln = (ctypes.c_int32 * c)(); self.ms = (ctypes.c_double * c)()
+        self.fl = (ctypes.c_double * c)(); self.by = (ctypes.c_double * c)(); self.nr = ctypes.c_int32(0)
+
+    def read(self):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.ulib.check(self.L.ucdir_profile_read(self.CAP, self.keys, self.ln, self.ms, self.fl, self.by,
+                                                  ctypes.byref(self.nr), st))
+        rows = [dict(key=int(self.keys[i]), kernel=KEY_NAMES.get(int(self.keys[i]), str(self.keys[i])),
+                     launches=int(self.ln[i]), ms=float(self.ms[i]), flops=float(self.fl[i]), bytes=float(self.by[i]))
+                for i in range(self.nr.value)]
+        rows.sort(key=lambda r: -r["ms"])
+        return rows
+
+
+def roofline_record(rows, whole_tflops=None):
+    """`roofline` object of the JSON line for the instantiation with the largest total time."""
+    if not rows:
+        return None
+    d = rows[0]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes / launch (see DESIGN.md)
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(d["kernel"])
+        except Exception:
+            traffic = None
+    roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+            "flops_per_launch": d["flops"] / d["launches"], "bytes_per_launch": d["bytes"] / d["launches"],
+            "all_kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
+                             "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)} for r in rows]}
+    if whole_tflops is not None:
+        roof["forward_tflops_whole"] = whole_tflops
+    return roof
+
+
 def latency_leg(net, dev, T):
     """B = 1 restorations with the forward replayed from a HIP graph: 256^2 (UNet at 288^2) and the DDPM.test size
     (256^2 crop reflect-padded by 64 -> 384^2 input, UNet at 416^2; the reference's val loader is batch_size = 1)."""
@@ -111,6 +157,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["replicas", "patch"], default="replicas")
     ap.add_argument("--latency", action="store_true", help="add B = 1 HIP-graph latency numbers to the JSON line")
+    ap.add_argument("--patch-batch", type=int, default=0, help="patch mode: windows per engine call (0 = the module's default)")
     ap.add_argument("--height", type=int, default=1424)
     ap.add_argument("--width", type=int, default=2128)
     args = ap.parse_args()
@@ -171,12 +218,8 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             net.super_resolution(cond, False)
-        # drop warm-up profile rows
-        cap = 32
-        keys = (ctypes.c_int32 * cap)(); ln = (ctypes.c_int32 * cap)(); ms = (ctypes.c_double * cap)()
-        fl = (ctypes.c_double * cap)(); by = (ctypes.c_double * cap)(); nr = ctypes.c_int32(0)
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        ulib.check(L.ucdir_profile_read(cap, keys, ln, ms, fl, by, ctypes.byref(nr), st))
+        prof = LaunchProfile(L, ulib)
+        prof.read()                                            # drop warm-up profile rows
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -189,32 +232,12 @@ def main():
     elapsed = float(elapsed.item())
     assert torch.isfinite(out).all()
 
-    ulib.check(L.ucdir_profile_read(cap, keys, ln, ms, fl, by, ctypes.byref(nr), st))
-    rows = [dict(key=int(keys[i]), kernel=KEY_NAMES.get(int(keys[i]), str(keys[i])), launches=int(ln[i]),
-                 ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(nr.value)]
-    rows.sort(key=lambda r: -r["ms"])
+    rows = prof.read()
 
     if rank == 0:
         fwd_flops = net.denoise_fn.forward_flops()          # algorithmic FLOPs of one B-sample forward
         value = world * B * args.steps / elapsed
-        roof = None
-        if rows:
-            d = rows[0]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes / launch
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(d["kernel"])
-                except Exception:
-                    traffic = None
-            roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                    "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                    "flops_per_launch": d["flops"] / d["launches"], "bytes_per_launch": d["bytes"] / d["launches"],
-                    "all_kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
-                                     "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)} for r in rows],
-                    "forward_tflops_whole": fwd_flops * T * args.steps / elapsed / 1e12}
+        roof = roofline_record(rows, fwd_flops * T * args.steps / elapsed / 1e12)
         rec = {"metric": "restored images/sec at 50-step p_sample_loop, 256x256 SID", "value": value,
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -244,11 +267,30 @@ def patch_mode(args, net, dev, dist, rank, world, T):
     if dist is not None:
         net.denoise_fn.patch_group = dist.group.WORLD
     net.noise_seed = 1234                                     # every rank applies the identical sampler update
+    if args.patch_batch:
+        net.denoise_fn.patch_max_batch = args.patch_batch
     cond = torch.from_numpy(synth_inputs(1, H, W, seed=0)[0]).to(dev)
     sr = F.pad(cond, (64, 64, 64, 64), mode="reflect")         # DDPM.test (model/model.py:127-128)
     pd = patch.patch_pad(sr.shape[-2], sr.shape[-1], net.denoise_fn.patch_skip, net.denoise_fn.patch_padding)
     nwin = len(patch.patch_windows(sr.shape[-2] + 2 * pd, sr.shape[-1] + 2 * pd, net.denoise_fn.patch_skip,
                                    net.denoise_fn.patch_padding))
+
+    from ucdir_amd import lib as ulib
+    L = ulib.load()
+    calls = {"n": 0}
+    inner = net.denoise_fn.forward                             # one call per sampler step: all of this rank's windows
+
+    def wrapped(*a, **k):                                      # HIP-event brackets around the launches of ONE step per image
+        on = (calls["n"] % T) == T // 2
+        calls["n"] += 1
+        if on:
+            L.ucdir_profile_enable(1)
+        try:
+            return inner(*a, **k)
+        finally:
+            if on:
+                L.ucdir_profile_enable(0)
+    net.denoise_fn.forward = wrapped
 
     def sync():
         if dist is not None:
@@ -257,20 +299,22 @@ def patch_mode(args, net, dev, dist, rank, world, T):
     with torch.no_grad():
         for _ in range(args.warmup):
             net.super_resolution(sr, False)
+        prof = LaunchProfile(L, ulib)
+        prof.read()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = net.super_resolution(sr, False)
         sync()
         t1 = time.perf_counter()
+    rows = prof.read()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert torch.isfinite(out).all()
     if rank == 0:
-        from ucdir_amd import lib as ulib
-        ws = ulib.load().ucdir_workspace_bytes(net.denoise_fn._handle())
+        ws = L.ucdir_workspace_bytes(net.denoise_fn._handle())
         rec = {"metric": f"restored full-resolution images/sec at {T}-step p_sample_loop, inter-step patch split",
                "value": args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -279,8 +323,9 @@ def patch_mode(args, net, dev, dist, rank, world, T):
                                       f"1024^2 per step (skip 1024, padding 64), {T}-step sampler; windows sharded over "
                                       f"{world} rank(s), one all-gather per step",
                           "global_batch": 1, "timesteps": T, "parallelism": f"patch-shard x{world}",
-                          "windows_per_step": nwin, "workspace_bytes_rank0": int(ws)},
-               "roofline": None}
+                          "windows_per_step": nwin, "windows_per_engine_batch": int(net.denoise_fn.patch_max_batch),
+                          "workspace_bytes_rank0": int(ws)},
+               "roofline": roofline_record(rows)}
         print(json.dumps(rec))
     if dist is not None:
         dist.barrier()

@@ -88,7 +88,7 @@ class DY3h(nn.Module):
         self.patch_threshold = 1024 * 1024   # model/ucdir.py:298
         self.patch_skip, self.patch_padding = 1024, 64
         self.patch_group = None              # torch.distributed group: windows of a step are sharded over its ranks
-        self.patch_max_batch = 4             # windows per engine call (1024^2 windows: 2.3 GB of workspace each)
+        self.patch_max_batch = 8             # windows per engine call (1024^2 windows: 2.3 GB of workspace each)
         self.use_graph = False               # replay each forward from a HIP graph (B = 1 latency path)
         self._h = None
         self._wdirty = True                  # parameters changed since the engine packed them
