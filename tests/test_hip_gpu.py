@@ -304,8 +304,8 @@ def test_checkpoint_roundtrip(tmp_path):
 
 @pytest.mark.gpu
 def test_alternative_kernel_paths_agree():
-    """The default dispatch (resident-weight AKGM, LDS-resident modulation weights, res_conv fused as a 10th tap,
-    fused final conv) and the plain kernels behind the UCDIR_NO_* switches compute the same forward: both are run
+    """The default dispatch (resident-weight AKGM, LDS-resident modulation weights, res_conv fused as a 10th tap or as tail
+    workgroups of conv1's launch, fused final conv, split-K on small grids, flash attention) and the plain kernels behind the UCDIR_NO_* switches compute the same forward: both are run
     against the oracle in fresh processes (the switches are read once per process)."""
     import json
     import subprocess
@@ -313,7 +313,8 @@ def test_alternative_kernel_paths_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for tag, env_extra in (("default", {}), ("plain", {"UCDIR_NO_PRE": "1", "UCDIR_NO_ATTLDS": "1", "UCDIR_NO_FUSED_RES": "1",
-                                                       "UCDIR_NO_FUSED_FINAL": "1"})):
+                                                       "UCDIR_NO_FUSED_FINAL": "1", "UCDIR_NO_TAIL_RES": "1", "UCDIR_SPLITK": "0",
+                                                       "UCDIR_NO_FLASH": "1"})):
         env = dict(os.environ); env.update(env_extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py"), "small"], env=env, capture_output=True,
                            text=True, timeout=600)

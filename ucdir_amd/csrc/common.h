@@ -167,5 +167,9 @@ struct GemmP {
     // channel chunks and writes raw fp32 accumulators to partial [wg][ksplit][256 px][TM]; conv_splitk_finish_kernel sums them
     // in a FIXED order (bit-reproducible) and runs the epilogue
     int ksplit; float* partial;
+    // conv3x3_halo tail filler: the last alt_blocks workgroups of the grid run the block's 1x1 res_conv on the same input
+    // (weights alt_A [rows][alt_a_ld], bias2, output out2): dispatched last, they fill the CUs the 3x3 conv's last partial
+    // round of workgroups leaves idle instead of waiting for it in a launch of their own
+    int alt_blocks; const bf16_t* alt_A; int alt_a_ld;
     unsigned long long* dbg;                // UCDIR_TIMING builds: s_memtime stamps of one workgroup
 };

@@ -78,11 +78,18 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: no waterfall loops around global_load_lds
     const int wm = wave / NPG, wq = wave % NPG;
     int lid;
+    bool alt = false;                                            // tail filler: this workgroup computes the 1x1 res_conv
     {
-        const int nblk = gridDim.x, bid = blockIdx.x;
+        int nblk = gridDim.x, bid = blockIdx.x;
+        if (!DUAL && p.alt_blocks) {
+            const int nmain = nblk - p.alt_blocks;
+            if (bid >= nmain) { alt = true; bid -= nmain; nblk = p.alt_blocks; } else nblk = nmain;
+        }
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const bool fold = p.fold && !alt;
+    const float* const bias = alt ? p.bias2 : p.bias;
     const int ksplit = DUAL ? 1 : p.ksplit;                               // (the fused-res_conv variant has no register to spare)
     int split = 0;
     if (ksplit > 1) { split = lid % ksplit; lid /= ksplit; }       // the splits of a tile are neighbours (same XCD)
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     // GroupNorm statistics of the input + fold table of this workgroup's rows (split-K workgroups have no epilogue: no table)
     auto build_table = [&]() {
         float mean = 0.f, rstd = 1.f;
-        if (p.fold) {
+        if (fold) {
             double S, Q;
             stat_read(p.stats0, p.stats1, b, S, Q);
             mean_rstd(S, Q, p.inv_count, mean, rstd);
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             const int cls = i / TM, fl = i - cls * TM;
             const int f = rowtile * TM + fl;
             float v = 0.f;
-            if (f < p.nfeat || p.bias) v = p.bias ? p.bias[f] : 0.f;
-            if (p.fold && f < p.nfeat) v += p.Tb[(long long)cls * p.tab_ld + f] - mr * p.Tg[(long long)cls * p.tab_ld + f];
+            if (f < p.nfeat || bias) v = bias ? bias[f] : 0.f;
+            if (fold && f < p.nfeat) v += p.Tb[(long long)cls * p.tab_ld + f] - mr * p.Tg[(long long)cls * p.tab_ld + f];
             tcs[i] = v;
         }
     };
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     // DUAL (64-row tiles only): a second accumulator set carries the block's res_conv as a 10th tap
     static_assert(!DUAL || TM == 64, "fused res_conv needs the 64-row tile");
     constexpr bool res_fused = DUAL;
-    const int ntap = p.up_phase ? 4 : (res_fused ? 10 : 9);   // tap 9 = the block's 1x1 res_conv on the centre pixel
+    const int ntap = alt ? 1 : (p.up_phase ? 4 : (res_fused ? 10 : 9));   // tap 9 = the block's 1x1 res_conv on the centre pixel
     const int nsteps_c = (ntap + TPS - 1) / TPS;   // steps per chunk
     const int nk = (nchunks - cbeg) * nsteps_c;
     auto issue_halo = [&](int c, int buf) {
@@ -176,10 +183,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         const int row = (k % (TM / 16)) * 16 + (lane >> 2);
         const int ajsw = (lane & 3) ^ ((row >> 2) & 3);
         atap[j] = k / (TM / 16);
-        arow_off[j] = (rowtile * TM + row) * p.a_ld + ajsw * 8;
+        arow_off[j] = (rowtile * TM + row) * (alt ? p.alt_a_ld : p.a_ld) + ajsw * 8;
         adst[j] = atap[j] * (TM * 64) + (k % (TM / 16)) * 1024;
     }
-    const bf16_t* Abase = p.A + (long long)par * p.a_gstride;
+    const bf16_t* Abase = alt ? p.alt_A : p.A + (long long)par * p.a_gstride;
     auto issue_A = [&](int c, int u, int slot) {      // taps TPS*u .. TPS*u+TPS-1 (tail taps re-stage the last valid one)
         unsigned char* ab = aring + slot * ASTAGE;
 #pragma unroll
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 const bool is_res = DUAL && t == 9;                 // wave-uniform
                 int sh;
                 if (p.up_phase) sh = (py + (t >> 1)) * hw + (pxp + (t & 1));
-                else if (is_res) sh = hw + 1;
+                else if (is_res || alt) sh = hw + 1;
                 else { const int ky = tap_ky(t); sh = ky * hw + (t - 3 * ky); }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -304,7 +311,11 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
 
     // ---- epilogue in passes of PXH pixels ------------------------------------------------------------
     const float rstd_s = scal[1];
-    const float alpha = p.alpha * (p.fold ? rstd_s : 1.0f);
+    const float alpha = alt ? 1.0f : p.alpha * (fold ? rstd_s : 1.0f);
+    const int act = alt ? 0 : p.act;
+    const bf16_t* const resp = alt ? nullptr : p.res;
+    bf16_t* const outp = alt ? p.out2 + (long long)b * p.out2_bstride : reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + p.out_coff;
+    const int out_ld = alt ? p.out2_ld : p.out_ld;
     const int fbase = rowtile * TM;
     constexpr int nf8 = TM / 8;
     float s1 = 0.f, s2 = 0.f;
@@ -355,15 +366,15 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 const float4 t1 = *reinterpret_cast<const float4*>(&tcs[cls * TM + f8 + 4]);
                 v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
             }
-            if (p.act == 1) {                      // one uniform branch per item, not one per element
+            if (act == 1) {                        // one uniform branch per item, not one per element
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
-            } else if (p.act == 2) {
+            } else if (act == 2) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
             }
-            if (p.res) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);
+            if (resp) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(resp + (long long)b * p.res_bstride + cp * p.res_ld + p.res_coff + f);
                 const bf16_t* rh = reinterpret_cast<const bf16_t*>(&rv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] += bf2f(rh[i]);
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                         if (f + i < p.nfeat) op[(long long)i * p.crop_h * p.crop_w] = v[i];
                 }
             } else {
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + cp * p.out_ld + p.out_coff + f) = pack8_bf16(v);
+                *reinterpret_cast<uint4*>(outp + cp * out_ld + f) = pack8_bf16(v);
             }
         }
     }
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
-    if (p.stats_out) {
+    if (p.stats_out && !alt) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
         __syncthreads();

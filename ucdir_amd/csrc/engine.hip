@@ -276,7 +276,7 @@ static void choose_tile(int H, int W, int& th, int& tw) {
 template <int TM, bool DUAL = false>
 static void launch_halo(const GemmP& p, hipStream_t st) {
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1) * ks;
+    const int nblk = p.nbatch * p.tiles_x * p.tiles_y * p.rowtiles * (p.up_phase ? 4 : 1) * ks + p.alt_blocks;
     auto finish = [&]() {
         if (ks == 1) return;
         const long long items = (long long)p.H * p.W * (p.up_phase ? 4 : 1) * (p.nfeat / 8);
@@ -330,7 +330,7 @@ static int choose_ksplit(int wgs, int nchunks) {
 // res_out != nullptr asks for the block's res_conv output from the same launch; returns true if it was produced
 static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
                      bool want_stats, hipStream_t st, float* nchw_out = nullptr, int crop_h = 0, int crop_w = 0,
-                     Act* res_out = nullptr) {
+                     Act* res_out = nullptr, const ConvW* wres = nullptr) {
     GemmP p; zero_gemm(p);
     const int cin = x0.C + (x1 ? x1->C : 0);
     require(cin == w.cin, "run_conv: channel mismatch");
@@ -392,11 +392,22 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         p.out2 = res_out->p; p.out2_bstride = res_out->bstride(); p.out2_ld = res_out->C;
         did_res = true;
     }
+    const bool dual = did_res;                          // conv3x3_halo_kernel<64, true>: second accumulator set
     if (halo && !did_res && !p.out_nchw && w.cout % 8 == 0) {
         const int ks = choose_ksplit(p.nbatch * p.tiles * p.rowtiles, cin / HC_BK);
         if (ks > 1) { p.ksplit = ks; p.partial = splitk_scratch(); }
     }
-    if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else if (did_res) launch_halo<64, true>(p, st); else launch_halo<64>(p, st); }
+    // 128-row tiles have no registers for a second accumulator set: the block's 1x1 res_conv rides in the same LAUNCH instead,
+    // as extra workgroups behind the 3x3 ones (same input, one tap) that fill the last, partly empty round of the grid
+    static const bool tail_res = !getenv("UCDIR_NO_TAIL_RES");
+    if (halo && !upph && !did_res && p.ksplit <= 1 && res_out && wres && tail_res && !p.out_nchw && wres->ntaps == 1 &&
+        wres->rows_pad >= p.rowtiles * tm_run) {
+        p.alt_blocks = p.nbatch * p.tiles * p.rowtiles;
+        p.alt_A = wres->A; p.alt_a_ld = wres->Kpad; p.bias2 = wres->bias;
+        p.out2 = res_out->p; p.out2_bstride = res_out->bstride(); p.out2_ld = res_out->C;
+        did_res = true;
+    }
+    if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else if (dual) launch_halo<64, true>(p, st); else launch_halo<64>(p, st); }
     else launch_cgemm(p, w.TM, EPI_STD, st);
 #ifdef UCDIR_TIMING
     if (halo) {
@@ -1012,7 +1023,7 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
             const Act* x0 = cur; const Act* x1 = nullptr;
             if (d.skip_c) { x1 = skips.back(); skips.pop_back(); require(x1->C == d.skip_c, "skip channel mismatch"); }
             // h1 = swish(conv1(GN1(cat[x0,x1])))
-            const bool res_done = run_conv(w.conv, *x0, x1, r.h1, COLS_S1, 1, nullptr, true, st, nullptr, 0, 0, w.has_res ? &r.res : nullptr);
+            const bool res_done = run_conv(w.conv, *x0, x1, r.h1, COLS_S1, 1, nullptr, true, st, nullptr, 0, 0, w.has_res ? &r.res : nullptr, w.has_res ? &w.resconv : nullptr);
             const Act* res = x0;
             if (w.has_res) { if (!res_done) run_conv(w.resconv, *x0, x1, r.res, COLS_S1, 0, nullptr, false, st); res = &r.res; }
             Act& bo = d.attn ? r.bo : r.out;
