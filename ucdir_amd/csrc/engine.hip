@@ -451,7 +451,15 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.usplit = 1;
     if (w.cg == 64 && !pre) {              // grids that leave CUs idle: one workgroup per 2 | 1 of a group's 4 units instead of all 4
-        if (splitk_on()) p.usplit = (nblk * 4 <= SPLITK_MAX_WGS) ? 4 : ((nblk * 2 <= SPLITK_MAX_WGS) ? 2 : 1);
+        if (splitk_on()) {
+            // rounds of 512 resident workgroups x length of a workgroup (its share of the 4 units + ~10 % fixed cost): e.g. B = 16
+            // at 36^2: 768 workgroups of 4 units = 2 rounds with the second half empty, 1536 of 2 units = 3 full short ones
+            double best = 1e30;
+            for (int us = 1; us <= 4; us *= 2) {
+                const double cost = (double)((nblk * us + SPLITK_MAX_WGS - 1) / SPLITK_MAX_WGS) * (1.0 / us + 0.10);
+                if (cost < best - 1e-9) { best = cost; p.usplit = us; }
+            }
+        }
         nblk *= p.usplit;
     }
     p.dbg = nullptr;
