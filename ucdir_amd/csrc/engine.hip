@@ -286,6 +286,11 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
 
     if (g_prof.on) {
         ProfEntry e; e.key = (TM == 128 ? 120 : 20) + (p.up_phase ? 1 : 0) + (DUAL ? 2 : 0); gemm_work(p, EPI_STD, e.flops, e.bytes);
+        if (p.alt_blocks) {        // the 1x1 res_conv riding in this launch: same input (counted once), its own weights and output
+            const double cols = (double)p.H * p.W * p.nbatch;
+            e.flops += 2.0 * p.cg * p.nfeat * cols;
+            e.bytes += 2.0 * p.cg * p.nfeat + 2.0 * p.nfeat * cols;
+        }
         e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
