@@ -310,6 +310,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     }
 
     // ---- epilogue in passes of PXH pixels ------------------------------------------------------------
+    // (The register epilogue of the AKGM kernels - v_permlane32_swap hands a lane 8 consecutive rows of one pixel, no LDS stage,
+    // no barriers - was built for this kernel too in round 2: bit-identical results, same-box A/B 29.10 vs 29.21 img/s for
+    // the staged version.  Here a wave's 16-byte stores land 2 x C_out bytes apart per lane, the staged pass writes whole
+    // pixel rows; kept staged.)
     const float rstd_s = scal[1];
     const float alpha = alt ? 1.0f : p.alpha * (fold ? rstd_s : 1.0f);
     const int act = alt ? 0 : p.act;
