@@ -24,3 +24,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests: a fixed number collides with a
+    previous run's sockets in TIME_WAIT or with a second pytest on the same host)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -124,7 +124,8 @@ def test_patch_split_sharded_over_ranks_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29611 + world
+    from conftest import free_port
+    port = free_port()
     procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -190,7 +191,9 @@ def test_dy3h_forward_shards_windows_over_ranks_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dy3h_worker, args=(r, 2, 29655, q)) for r in range(2)]
+    from conftest import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_dy3h_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=180) for _ in range(2))

@@ -362,7 +362,9 @@ def test_sharded_restoration_two_gpus_equals_one():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_nccl_patch_worker, args=(r, 2, 29671, q)) for r in range(2)]
+    from conftest import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_nccl_patch_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=600) for _ in range(2))

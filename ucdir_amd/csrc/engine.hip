@@ -170,7 +170,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv3x3_halo_kernel<64, false>, hc_lds_bytes<64>());
     set_lds_attr(conv3x3_halo_kernel<64, true>, hc_lds_bytes<64>());
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
-    set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS); set_lds_attr(akgm_pre_kernel<16>, AkPre<16>::LDS);
+    set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
