@@ -315,20 +315,28 @@ static float* splitk_scratch() {
     require(it != g_splitk_buf.end(), "split-K scratch not allocated on this device");
     return it->second;
 }
-// number of K splits for a conv3x3_halo grid of `wgs` workgroups over `nchunks` 32-channel chunks: fill ~2 workgroups per CU,
-// at least three chunks per split.  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
+// number of K splits for a conv3x3_halo grid of `wgs` workgroups over `nchunks` 32-channel chunks (at most 512 workgroups, at
+// least two chunks per split).  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
 static int g_splitk = -1;           // -1: environment (UCDIR_SPLITK=0 disables), 0 / 1: ucdir_debug_flag("splitk", v)
 static bool splitk_on() {
     static const bool env_on = !(getenv("UCDIR_SPLITK") && atoi(getenv("UCDIR_SPLITK")) == 0);
     return g_splitk < 0 ? env_on : g_splitk != 0;
 }
-static int choose_ksplit(int wgs, int nchunks) {
+// Cost model in microseconds, fitted to B = 1 kernel traces (profiles/r02_b1_forward_trace.txt): a K step costs ~1.0 us while a
+// CU holds one workgroup (1.3 with two), the finish launch ~5 us + its partial-tile traffic at ~1.5 TB/s.  Deep levels (long
+// K, few outputs) split 8-16 ways; the 144^2 level (10 MB of partial sums per split) never does.
+static int choose_ksplit(int wgs, int nchunks, int steps_per_chunk, double out_elems) {
     static const int lim = getenv("UCDIR_SPLITK_WGS") ? atoi(getenv("UCDIR_SPLITK_WGS")) : 256;
     if (!splitk_on() || wgs > lim || wgs <= 0) return 1;
-    int ks = SPLITK_MAX_WGS / wgs;
-    if (ks > nchunks / 3) ks = nchunks / 3;             // at least three chunks (7 - 9 K steps) per split
-    if (ks > 16) ks = 16;
-    return ks < 2 ? 1 : ks;
+    const double unsplit = (double)nchunks * steps_per_chunk * (wgs > 256 ? 1.3 : 1.0);
+    int best = 1;
+    double best_cost = 0.85 * unsplit;                  // a split has to be clearly worth its second launch
+    for (int ks = 2; ks <= 16 && wgs * ks <= SPLITK_MAX_WGS && nchunks / ks >= 2; ++ks) {
+        const double steps = (double)((nchunks + ks - 1) / ks) * steps_per_chunk * (wgs * ks > 256 ? 1.3 : 1.0);
+        const double cost = steps + 5.0 + out_elems * 4.0 * ks / 1.5e6;
+        if (cost < best_cost) { best_cost = cost; best = ks; }
+    }
+    return best;
 }
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
@@ -399,7 +407,9 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     }
     const bool dual = did_res;                          // conv3x3_halo_kernel<64, true>: second accumulator set
     if (halo && !did_res && !p.out_nchw && w.cout % 8 == 0) {
-        const int ks = choose_ksplit(p.nbatch * p.tiles * p.rowtiles, cin / HC_BK);
+        const int taps = upph ? 4 : 9, tps = 256 / tm_run;
+        const int ks = choose_ksplit(p.nbatch * p.tiles * p.rowtiles, cin / HC_BK, (taps + tps - 1) / tps,
+                                     (double)y.B * y.H * y.W * w.cout);
         if (ks > 1) { p.ksplit = ks; p.partial = splitk_scratch(); }
     }
     // 128-row tiles have no registers for a second accumulator set: the block's 1x1 res_conv rides in the same LAUNCH instead,
@@ -559,7 +569,7 @@ static void alloc_attn(DevPool& pool, AttnBufs& a, int B, int N, int C, bool hal
     // a handful of query blocks (B = 1 at the 36^2 / 18^2 levels: 11 / 3 workgroups on 256 CUs, each walking every KV tile
     // alone) is the one case the three-launch materialised path wins (94 -> ~55 us at N = 1296); its score tensors are
     // small there by construction.  An explicit ucdir_debug_flag("flash", 1) keeps the flash kernel (tests).
-    if (a.flash && !half && g_flash < 0 && B * ((N + FA_BQ - 1) / FA_BQ) < 32 && N <= 2048) a.flash = false;
+    if (a.flash && !half && g_flash < 0 && B * ((N + FA_BQ - 1) / FA_BQ) < 32) a.flash = false;   // (N < 4096: scores <= 100 MB)
     require(a.flash || !half, "fp16 attention operands need the flash kernel (C % 128 == 0, C <= 512)");
     a.qkv = (bf16_t*)pool.alloc((size_t)B * N * 3 * C * 2);
     if (!a.flash) {
