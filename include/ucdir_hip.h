@@ -111,13 +111,15 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
 /* ---- introspection (tests / profiling) ---------------------------------------------------
  * Copy the activation a layer produced in the last forward into dst as (B,C,Hc,Wc) fp32 NCHW
  * (Hc, Wc = compute size).  layer = state_dict prefix ("downs.0", "ups.7", "mid.0", ...),
- * what = "out" (layer output) or "h1" (swish(conv1) inside a block). */
+ * what = "out" (layer output), "h1" (swish(conv1) inside a block), or "attw" (a block's eight time weights,
+ * noise_func(noise_level_mlp(PosEnc(level))), (B,8) fp32: model/ucdir.py:24-29,106,125,212-214). */
 int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, float* dst,
                          int64_t dst_elems, void* stream);
 int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
 /* Process-wide test switches, read when a shape is planned / an op entry point runs.
  * "flash": 1 = flash-attention kernel, 0 = materialised-score path (QK^T, softmax, PV as three launches),
- * -1 = environment default (UCDIR_NO_FLASH).  Unknown names are an error. */
+ * -1 = environment default (UCDIR_NO_FLASH).  "splitk": 1 / 0 / -1 the same for split-K and unit splits of
+ * under-filled grids (UCDIR_SPLITK).  Unknown names are an error. */
 int32_t ucdir_debug_flag(const char* name, int32_t value);
 /* Per-launch HIP-event timing of the GEMM-core kernels (bench.py's roofline leg).  While enabled,
  * every launch is bracketed by events on its stream; ucdir_profile_read synchronises the stream and

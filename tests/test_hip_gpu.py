@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import hip_checks as C  # noqa: E402
+from oracle import ucdir_oracle as O  # noqa: E402
 from ucdir_amd.spec import UNetConfig  # noqa: E402
 
 SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn_res=(32,), image_size=128)
@@ -97,6 +98,30 @@ def test_forward_sid_full_config(golden_dir, sid_net):
     gm = C.metrics(crop, torch.from_numpy(g["eps1_crop"]))
     print("full SID forward vs oracle:", out["eps"], " crop vs reference golden:", gm)
     assert gm["rel_rms"] < CROP_TOL, gm
+
+
+def test_time_embedding_direct(sid_net):
+    """PositionalEncoding + noise_level_mlp + every block's noise_func (model/ucdir.py:24-29, 106, 125, 212-214) as computed by
+    time_mlp_kernel (fp32), read back per block, against the oracle - over the whole range of noise levels the schedule produces."""
+    net, sd = sid_net
+    from ucdir_amd.spec import unet_layers
+    from ucdir_amd.weights import synth_inputs
+    B = 4
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(B, 64, 64, seed=2))
+    lvl = torch.tensor([[1e-4], [0.03], [0.5], [0.9999]])
+    with torch.no_grad():
+        net.denoise_fn(torch.cat([cond, x_t], 1).cuda(), lvl.cuda(), guide.cuda())
+    temb = O.noise_embedding(sd, lvl, "denoise_fn.")
+    worst, n = 0.0, 0
+    for Ld in unet_layers(net.denoise_fn.cfg):
+        if Ld.kind != "block":
+            continue
+        got = net.denoise_fn.debug_read(Ld.name, "attw").cpu()
+        ref = O.time_weights(sd, "denoise_fn." + Ld.name + ".res_block.", temb)
+        assert got.shape == ref.shape == (B, 8)
+        worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+        n += 1
+    assert n == 27 and worst < 2e-5, (n, worst)      # fp32 both sides: __sinf / __expf vs libm
 
 
 def test_forward_batch_is_independent(sid_net):

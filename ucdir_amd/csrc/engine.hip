@@ -1233,6 +1233,13 @@ int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, fl
     for (size_t li = 0; li < ctx->layers.size(); ++li) {
         if (ctx->layers[li].name != layer) continue;
         const LayerRT& r = ctx->rt[li];
+        if (!strcmp(what, "attw")) {          // the block's time weights noise_func(PosEnc + MLP(level)) [B][8] (time_mlp_kernel, fp32)
+            require(ctx->layers[li].kind == "block" && ctx->attw != nullptr, "attw: not a residual block");
+            require(dst_elems == (int64_t)ctx->B * 8, "debug_read: attw has B * 8 elements");
+            HIPC(hipMemcpyAsync(dst, ctx->attw + (size_t)ctx->lw[li].block_index * ctx->B * 8, sizeof(float) * ctx->B * 8,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            return 0;
+        }
         const Act* a = &r.out;
         if (!strcmp(what, "h1")) a = &r.h1;
         else if (!strcmp(what, "res")) a = &r.res;

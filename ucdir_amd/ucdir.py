@@ -229,6 +229,11 @@ class DY3h(nn.Module):
         from .spec import unet_layers
         B, Hc, Wc = self._last_shape
         for Ld in unet_layers(self.cfg):
+            if Ld.name == layer and what == "attw":       # the block's time weights, (B, 8) fp32
+                out = torch.empty(B, 8, device=next(self.parameters()).device)
+                _lib.check(L.ucdir_debug_read(self._handle(), layer.encode(), b"attw", _ptr(out), out.numel(),
+                                              _stream_ptr(self._dev())))
+                return out
             if Ld.name == layer:
                 lvl = Ld.level + (1 if Ld.kind == "down" else (-1 if Ld.kind == "up" else 0))
                 out = torch.empty(B, Ld.cout, Hc >> lvl, Wc >> lvl, device=next(self.parameters()).device)
