@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU session: environment-variable A/B on one build:  tools/gpu_session17.sh "VAR=a" "VAR=b" ...
+# GPU session: environment-variable A/B on one build:  tools/ab_env.sh "VAR=a" "VAR=b" ...
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 for i in 1 2 3; do
   for v in "$@"; do
@@ -8,5 +8,5 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(round(d['value'],2), ' '.join('%s:%.2f'%(k['kernel'][:14],k['ms']) for k in d['roofline']['all_kernels'][:9]))")"
   done
-done > gpurun_out/s17_ab.log 2>&1
-cat gpurun_out/s17_ab.log
+done > gpurun_out/abenv_ab.log 2>&1
+cat gpurun_out/abenv_ab.log
