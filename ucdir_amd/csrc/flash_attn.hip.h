@@ -14,7 +14,9 @@
 //              v_mfma_f32_32x32x16 (A = V't rows, B = P rows): 8 tiles = 128 accumulator registers.
 //   LDS      : K tile [64 keys][C] (64 KB) | V't tile [C][64 keys] (64 KB) | P [128][64] (16 KB) | row scalars.
 //              Both tiles arrive by LDS-DMA (global_load_lds, 16 B / lane) with the XOR swizzle on the SOURCE
-//              address; K(t+1) flies under PV(t), V't(t) under S(t): two barriers per KV tile.
+//              address; K(t+1) flies under PV(t), V't(t) under S(t): two barriers per KV tile.  (Requesting K(t+1) a phase
+//              earlier - third barrier after the S loop, counted vmcnt before PV - was measured: 5 % slower at N = 1296 and
+//              at N = 16384; K's latency is already covered by the PV phase, the barrier is not free.)
 // Epilogue: O / l + bias + residual -> zero-bordered NHWC bf16 + GroupNorm statistics of the output (stat_add).
 // Registers: O 128 + Q 64 of the 256 a wave has at two waves per SIMD; the S phase is software-pipelined by hand (the
 // fragment of step ks+1 is requested as soon as the MFMA of step ks has consumed its register: four LDS reads in
