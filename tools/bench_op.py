@@ -1,6 +1,7 @@
 """Micro-benchmark of single operators through the C ABI (for rocprofv3 --pmc runs).
   python tools/bench_op.py conv B H W cin cout [reps]      (3x3 stride-1 conv with GN fold + swish)
   python tools/bench_op.py akgm B H W C [reps]
+  python tools/bench_op.py attn B C H W [reps]
 """
 import ctypes, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,5 +32,19 @@ elif kind == "akgm":
     y = torch.empty(B, Cc, H, W, device="cuda")
     for _ in range(reps):
         ulib.check(L.ucdir_op_akgm(C._p(h), C._p(att), C._p(res), B, Cc, H, W, C._hp(wsp), C._hp(bsp), C._hp(gm), C._hp(bt), C._p(y), C._st()))
+    torch.cuda.synchronize()
+    print("done", float(y.abs().mean()))
+elif kind == "attn":        # python tools/bench_op.py attn B C H W [reps]   (flash kernel forced; UCDIR_LIB=timing build prints the phase stamps)
+    B, Cc, H, W = map(int, sys.argv[2:6]); reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+    g = C.rng(0)
+    x = (torch.randn(B, Cc, H, W, generator=g) * 1.2 + 0.3).cuda()
+    n = lambda t: t.numpy().copy()
+    gm, bt = n(1 + 0.25 * torch.randn(Cc, generator=g)), n(0.2 * torch.randn(Cc, generator=g))
+    wq = n(torch.randn(3 * Cc, Cc, 1, 1, generator=g) * math.sqrt(3.0 / Cc))
+    wo, bo = n(torch.randn(Cc, Cc, 1, 1, generator=g) * math.sqrt(1.5 / Cc)), n(torch.randn(Cc, generator=g) * 0.1)
+    y = torch.empty_like(x)
+    ulib.check(L.ucdir_debug_flag(b"flash", 1))
+    for _ in range(reps):
+        ulib.check(L.ucdir_op_attention(C._p(x), B, Cc, H, W, C._hp(gm), C._hp(bt), C._hp(wq), C._hp(wo), C._hp(bo), 0, C._p(y), C._st()))
     torch.cuda.synchronize()
     print("done", float(y.abs().mean()))

@@ -632,6 +632,13 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         f.res = x.p; f.res_bstride = x.bstride(); f.out = y.p; f.out_bstride = y.bstride();
         f.stats_out = y.stats;
         f.nq = (N + FA_BQ - 1) / FA_BQ;
+        f.dbg = nullptr;
+#ifdef UCDIR_TIMING
+        static unsigned long long* fdbg = nullptr;
+        if (!fdbg) HIPC(hipMalloc((void**)&fdbg, 256 * 8));
+        HIPC(hipMemset(fdbg, 0, 256 * 8));
+        f.dbg = fdbg;
+#endif
         const dim3 grid((unsigned)(B * f.nq));
         const size_t lds = fa_lds_bytes(C);
         auto launch = [&]() {
@@ -657,6 +664,17 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
             g_prof.entries.push_back(e);
         } else launch();
         HIPC(hipGetLastError());
+#ifdef UCDIR_TIMING
+        {   // per-tile phase anatomy of one wave: deltas between the six stamps of tiles 4 .. 7 (steady state)
+            unsigned long long h[256];
+            HIPC(hipStreamSynchronize(st));
+            HIPC(hipMemcpy(h, fdbg, sizeof(h), hipMemcpyDeviceToHost));
+            const int n = (int)h[255];
+            fprintf(stderr, "FLASH TIMING N=%d C=%d B=%d stamps=%d:", N, C, B, n);
+            for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, "\n");
+        }
+#endif
         return;
     }
     // 3. S[i][j] = q_i . k_j / sqrt(C)   (rows = keys j, cols = queries i)

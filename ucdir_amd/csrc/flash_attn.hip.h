@@ -42,7 +42,14 @@ struct FlashP {
     bf16_t* out; long long out_bstride;                     // y, zero-bordered NHWC
     stat_t* stats_out;
     int nq;                                                 // query tiles per sample
+    unsigned long long* dbg;                                // UCDIR_TIMING builds: s_memtime stamps of one wave
 };
+
+#ifdef UCDIR_TIMING
+#define FA_STAMP() do { if (dbg_on && dbg_n < 250) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FA_STAMP() do {} while (0)
+#endif
 
 #define FA_BQ 128
 #define FA_BK 64
@@ -129,6 +136,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         }
     };
 
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2) && (lane == 0) && (wave == 5);
+    int dbg_n = 0;
+#endif
+    FA_STAMP();
     issue_K(0);
 
     // ---- resident Q fragments of this wave's 16 queries: lane (x = lane & 15, g = lane >> 4) holds
@@ -166,8 +178,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
     constexpr int DPW = 32 * NC;                        // channels per wave in the PV phase
 
     for (int t = 0; t < ntiles; ++t) {
+        FA_STAMP();                                                 // [6k+1] tile start
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // K(t) (and, first time, Q) landed
+        FA_STAMP();                                                 // [6k+2] K wait done
         __syncthreads();                                            // ... for every wave; PV(t-1) done: P, V't free
+        FA_STAMP();                                                 // [6k+3] barrier A passed
         issue_V(t);
         // ---- S^T = K Q^T --------------------------------------------------------------------------------------
         f32x4_t sacc[4];
@@ -191,6 +206,10 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
             }
         }
         __builtin_amdgcn_s_setprio(0);
+#ifdef UCDIR_TIMING
+        asm volatile("" :: "v"(sacc[0][0]), "v"(sacc[3][3]));
+#endif
+        FA_STAMP();                                                 // [6k+4] S phase done
         // ---- online softmax of this wave's 16 rows ---------------------------------------------------------------
         if (t == ntiles - 1 && (N & (FA_BK - 1))) {
 #pragma unroll
@@ -222,8 +241,10 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         }
         l_run = l_run * alpha + psum;
         if (g == 0) rowsc[16 * wave + x] = alpha;
+        FA_STAMP();                                                 // [6k+5] softmax + P write done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // V't(t) landed
         __syncthreads();                                            // P, alpha visible; every wave done with K(t)
+        FA_STAMP();                                                 // [6k+6] V wait + barrier B passed
         if (t + 1 < ntiles) issue_K(t + 1);
         // ---- O^T = alpha O^T + V't P^T ----------------------------------------------------------------------------
         {
@@ -237,6 +258,10 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         }
         int vx = vxor;
         asm volatile("" : "+v"(vx));
+        // (Re-requesting each fragment register for step k16 + 1 right behind its last MFMA of step k16 - the S phase's trick,
+        // no extra registers - shortens this phase in the s_memtime stamps, 4780 -> 4160 cycles, and leaves the kernel's
+        // duration where it was at N = 1296 and N = 16384: with two waves per SIMD the phase is bound by the MFMA / LDS pipes
+        // the other wave shares, not by this wave's read latency.  Kept in the plain form.)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16) {
@@ -253,6 +278,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         __builtin_amdgcn_s_setprio(0);
     }
 
+#ifdef UCDIR_TIMING
+    asm volatile("" :: "v"(oacc[0][0][0]), "v"(oacc[NC - 1][1][15]));
+    FA_STAMP();
+    if (dbg_on) p.dbg[255] = dbg_n;
+#endif
     // ---- epilogue ----------------------------------------------------------------------------------------------------
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
