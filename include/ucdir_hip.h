@@ -121,6 +121,10 @@ int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
  * -1 = environment default (UCDIR_NO_FLASH).  "splitk": 1 / 0 / -1 the same for split-K and unit splits of
  * under-filled grids (UCDIR_SPLITK).  Unknown names are an error. */
 int32_t ucdir_debug_flag(const char* name, int32_t value);
+/* Host-side launch planning, callable without a device (tests): what = "ksplit" -> the K-split factor conv3x3_halo would use
+ * for a grid of `wgs` workgroups over `nchunks` 32-channel chunks of `steps_per_chunk` K steps producing `out_elems` outputs;
+ * what = "usplit" -> the unit split (1 | 2 | 4) of the 64-per-group AKGM kernel for `wgs` workgroups.  -1 on a bad name. */
+int32_t ucdir_debug_launch_plan(const char* what, int32_t wgs, int32_t nchunks, int32_t steps_per_chunk, double out_elems);
 /* Per-launch HIP-event timing of the GEMM-core kernels (bench.py's roofline leg).  While enabled,
  * every launch is bracketed by events on its stream; ucdir_profile_read synchronises the stream and
  * aggregates per kernel instantiation: key = 100*[TM==128] + 10*[AKGM epilogue] + column mode

@@ -305,3 +305,22 @@ def test_device_side_uint8_conversion_matches_tensor2img():
     t[0, 0, 0], t[1, 0, 0], t[2, 0, 0] = -1.0 + 1 / 255, 0.0, 1.0 - 1 / 255      # exact .5 cases round half to even
     np.testing.assert_array_equal(M.tensor2img_u8_device(t), M.tensor2img(t))
     np.testing.assert_array_equal(M.tensor2img_u8_device(t.unsqueeze(0)), O.tensor2img(t))
+
+
+def test_launch_plan_split_factors():
+    """Host-side launch planning of the engine (no device needed): the K-split of conv3x3_halo follows the cost model fitted to
+    the B = 1 traces - deep levels split 4-16 ways, the 144^2 level (10 MB of partial sums per split) and full grids never -
+    and the 64-per-group AKGM kernel spreads its units by whole rounds of 512 resident workgroups."""
+    from ucdir_amd import lib as ulib
+    L = ulib.load()
+    plan = L.ucdir_debug_launch_plan
+    assert plan(b"ksplit", 16, 32, 3, 324 * 512.0) == 16              # B = 1, 18^2, 1024 -> 512: 16 workgroups x 96 K steps
+    assert 2 <= plan(b"ksplit", 100, 16, 3, 72 * 72 * 256.0) <= 5     # B = 1, 72^2, 512 -> 256
+    assert plan(b"ksplit", 162, 12, 3, 144 * 144 * 128.0) == 1        # B = 1, 144^2: the finish pass would cost what the split saves
+    assert plan(b"ksplit", 256, 16, 3, 16 * 324 * 512.0) == 1         # B = 16, 18^2: one workgroup per CU already
+    assert plan(b"ksplit", 1296, 12, 5, 16 * 144 * 144 * 128.0) == 1  # full grids are never split
+    for wgs, nch in ((16, 32), (48, 24), (100, 8), (256, 32)):
+        ks = plan(b"ksplit", wgs, nch, 3, 1e5)
+        assert ks >= 1 and wgs * ks <= 512 and nch // ks >= 2 or ks == 1
+    assert [plan(b"usplit", n, 0, 0, 0.0) for n in (768, 256, 48, 16, 3072)] == [2, 2, 4, 4, 1]
+    assert plan(b"nonsense", 1, 1, 1, 0.0) == -1

@@ -339,6 +339,20 @@ static int choose_ksplit(int wgs, int nchunks, int steps_per_chunk, double out_e
     return best;
 }
 
+// 64-per-group AKGM: spread the 4 units of a group over 1 | 2 | 4 workgroups.  Cost = rounds of 512 resident workgroups x
+// length of a workgroup (its share of the 4 units + ~10 % fixed cost): e.g. B = 16 at 36^2: 768 workgroups of 4 units = 2 rounds
+// with the second half empty, 1536 of 2 units = 3 full short ones
+static int choose_usplit(int nblk) {
+    if (!splitk_on() || nblk <= 0) return 1;
+    int best_us = 1;
+    double best = 1e30;
+    for (int us = 1; us <= 4; us *= 2) {
+        const double cost = (double)((nblk * us + SPLITK_MAX_WGS - 1) / SPLITK_MAX_WGS) * (1.0 / us + 0.10);
+        if (cost < best - 1e-9) { best = cost; best_us = us; }
+    }
+    return best_us;
+}
+
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
 // res_out != nullptr asks for the block's res_conv output from the same launch; returns true if it was produced
 static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int mode, int act, const Act* res,
@@ -466,15 +480,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     int nblk = y.B * p.tiles_x * p.tiles_y * nsec;
     p.usplit = 1;
     if (w.cg == 64 && !pre) {              // grids that leave CUs idle: one workgroup per 2 | 1 of a group's 4 units instead of all 4
-        if (splitk_on()) {
-            // rounds of 512 resident workgroups x length of a workgroup (its share of the 4 units + ~10 % fixed cost): e.g. B = 16
-            // at 36^2: 768 workgroups of 4 units = 2 rounds with the second half empty, 1536 of 2 units = 3 full short ones
-            double best = 1e30;
-            for (int us = 1; us <= 4; us *= 2) {
-                const double cost = (double)((nblk * us + SPLITK_MAX_WGS - 1) / SPLITK_MAX_WGS) * (1.0 / us + 0.10);
-                if (cost < best - 1e-9) { best = cost; p.usplit = us; }
-            }
-        }
+        p.usplit = choose_usplit(nblk);
         nblk *= p.usplit;
     }
     p.dbg = nullptr;
@@ -1280,6 +1286,16 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END
+}
+
+int32_t ucdir_debug_launch_plan(const char* what, int32_t wgs, int32_t nchunks, int32_t steps_per_chunk, double out_elems) {
+    // pure host logic (no device needed): the split factors the engine would pick for a grid
+    if (!what) return -1;
+    try {
+        if (!strcmp(what, "ksplit")) return choose_ksplit(wgs, nchunks, steps_per_chunk, out_elems);
+        if (!strcmp(what, "usplit")) return choose_usplit(wgs);
+    } catch (...) {}
+    return -1;
 }
 
 int32_t ucdir_profile_enable(int32_t on) {

@@ -43,6 +43,7 @@ _SIGS = {
     "ucdir_debug_read": (c_int32, [c_void_p, c_char_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "ucdir_workspace_bytes": (c_int64, [c_void_p]),
     "ucdir_debug_flag": (c_int32, [c_char_p, c_int32]),
+    "ucdir_debug_launch_plan": (c_int32, [c_char_p, c_int32, c_int32, c_int32, c_double]),
     "ucdir_profile_enable": (c_int32, [c_int32]),
     "ucdir_profile_read": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), POINTER(c_double),
                                      POINTER(c_double), POINTER(c_int32), c_void_p]),
