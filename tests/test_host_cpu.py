@@ -113,7 +113,7 @@ def _dist_worker(rank, world, port, q):
     torch.manual_seed(0)
     x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
     got = patch.patch_forward_guide(x, _toy_net, {"time": t, "guide": g}, skip=96, padding=16, group=dist.group.WORLD)
-    q.put((rank, got))
+    q.put((rank, got.numpy()))      # by value: a tensor travels as a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,7 +129,7 @@ def test_patch_split_sharded_over_ranks_gloo(world):
     procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=120) for _ in range(world))
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(60)
     torch.manual_seed(0)
@@ -180,7 +180,7 @@ def _dy3h_worker(rank, world, port, q):
     assert net.patch_group is dist.group.WORLD and holder.netG.noise_seed is not None
     torch.manual_seed(0)
     x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
-    q.put((rank, net(x, t, g)))
+    q.put((rank, net(x, t, g).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -196,7 +196,7 @@ def test_dy3h_forward_shards_windows_over_ranks_gloo():
     procs = [ctx.Process(target=_dy3h_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=180) for _ in range(2))
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=180) for _ in range(2))}
     for p in procs:
         p.join(60)
     torch.manual_seed(0)

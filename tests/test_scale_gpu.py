@@ -352,7 +352,7 @@ def _nccl_patch_worker(rank, world, port, q):
     cond = torch.from_numpy(synth_inputs(1, 160, 200, seed=5)[0]).cuda()
     with torch.no_grad():
         out = net.super_resolution(cond, False)
-    q.put((rank, out.cpu()))
+    q.put((rank, out.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -367,7 +367,7 @@ def test_sharded_restoration_two_gpus_equals_one():
     procs = [ctx.Process(target=_nccl_patch_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=600) for _ in range(2))
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=600) for _ in range(2))}
     for p in procs:
         p.join(60)
     net, sd = C.build_net(SMALL)
