@@ -90,7 +90,8 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     }
     const bool fold = p.fold && !alt;
     const float* const bias = alt ? p.bias2 : p.bias;
-    const int ksplit = DUAL ? 1 : p.ksplit;                               // (the fused-res_conv variant has no register to spare)
+    const int ksplit = (DUAL || alt) ? 1 : p.ksplit;                      // (the fused-res_conv variant has no register to spare;
+                                                                          //  tail workgroups run their short K loop whole)
     int split = 0;
     if (ksplit > 1) { split = lid % ksplit; lid /= ksplit; }       // the splits of a tile are neighbours (same XCD)
     const int wgid = lid;

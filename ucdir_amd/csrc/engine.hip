@@ -429,7 +429,7 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     // 128-row tiles have no registers for a second accumulator set: the block's 1x1 res_conv rides in the same LAUNCH instead,
     // as extra workgroups behind the 3x3 ones (same input, one tap) that fill the last, partly empty round of the grid
     static const bool tail_res = !getenv("UCDIR_NO_TAIL_RES");
-    if (halo && !upph && !did_res && p.ksplit <= 1 && res_out && wres && tail_res && !p.out_nchw && wres->ntaps == 1 &&
+    if (halo && !upph && !did_res && res_out && wres && tail_res && !p.out_nchw && wres->ntaps == 1 &&
         wres->rows_pad >= p.rowtiles * tm_run) {
         p.alt_blocks = p.nbatch * p.tiles * p.rowtiles;
         p.alt_A = wres->A; p.alt_a_ld = wres->Kpad; p.bias2 = wres->bias;
