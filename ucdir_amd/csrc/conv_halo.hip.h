@@ -488,8 +488,23 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const GemmP p, 
         long long wg = (((long long)b * p.tiles_y + ty) * p.tiles_x + tx) * p.rowtiles + rowtile;
         if (p.up_phase) wg = wg * 4 + par;
         const float* pb = p.partial + wg * p.ksplit * tile + (long long)slot * TM + fl;
+        // four splits per round trip (the loads of a group are independent: issued together, then added in split order)
         float4 a = *reinterpret_cast<const float4*>(pb), d = *reinterpret_cast<const float4*>(pb + 4);
-        for (int s = 1; s < p.ksplit; ++s) {
+        int s = 1;
+        for (; s + 3 < p.ksplit; s += 4) {
+            float4 aa[4], dd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                aa[j] = *reinterpret_cast<const float4*>(pb + (s + j) * tile);
+                dd[j] = *reinterpret_cast<const float4*>(pb + (s + j) * tile + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a.x += aa[j].x; a.y += aa[j].y; a.z += aa[j].z; a.w += aa[j].w;
+                d.x += dd[j].x; d.y += dd[j].y; d.z += dd[j].z; d.w += dd[j].w;
+            }
+        }
+        for (; s < p.ksplit; ++s) {
             const float4 a1 = *reinterpret_cast<const float4*>(pb + s * tile), d1 = *reinterpret_cast<const float4*>(pb + s * tile + 4);
             a.x += a1.x; a.y += a1.y; a.z += a1.z; a.w += a1.w; d.x += d1.x; d.y += d1.y; d.z += d1.z; d.w += d1.w;
         }
