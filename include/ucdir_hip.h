@@ -25,7 +25,9 @@
  *     every tensor it passes in;
  *   - every entry point that takes a handle runs on the handle's device and restores the calling
  *     thread's current HIP device before it returns; ucdir_sampler_step runs on the device that
- *     owns x_t; the single-operator test entry points (ucdir_op_*) use the current device.
+ *     owns x_t; the single-operator test entry points (ucdir_op_*) use the current device;
+ *   - the handles of one device share a 64 MiB split-K scratch: enqueue their work on ONE stream (as the sampler does:
+ *     predictor, then 50 x denoiser), or order the streams yourself.
  */
 #ifndef UCDIR_HIP_H
 #define UCDIR_HIP_H
