@@ -113,31 +113,56 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     int dbg_n = 0;
 #endif
     HC_STAMP(-1);                                               // kernel entry
-    // (Issuing the first halo / weight DMA ahead of this statistics + fold-table prologue was measured: the time to the first
-    // MFMA stayed at ~14k cycles - the ordinary loads below queue behind the DMA in the in-order VMEM path - and the 64-row
-    // launches got 10 % slower.  Kept in this order.)
-
-    // GroupNorm statistics of the input + fold table of this workgroup's rows (split-K workgroups have no epilogue: no table)
-    auto build_table = [&]() {
-        float mean = 0.f, rstd = 1.f;
-        if (fold) {
-            double S, Q;
-            stat_read(p.stats0, p.stats1, b, S, Q);
-            mean_rstd(S, Q, p.inv_count, mean, rstd);
+    // Prologue order (round 2): (1) the fold table's operands (bias, Tb, Tg of this thread's 9 TM / 512 entries) and the input's
+    // statistics slots (wave 0, one slot value per lane) are REQUESTED here, into registers; (2) the geometry below is computed
+    // and the first halo / weight DMAs are issued while they fly; (3) a counted wait - VMEM returns in order, the DMAs behind
+    // them stay in flight - then mean / rstd, one barrier, and the table goes to LDS.  One memory round trip before the first
+    // MFMA instead of three (statistics -> table operands -> DMA): ~12 k -> ~5 k cycles.  (Issuing the DMA FIRST was measured in
+    // round 2 and did not help: the ordinary loads then queue behind it in the in-order VMEM path.)
+    constexpr int NE = (9 * TM + HC_THREADS - 1) / HC_THREADS;
+    float te_b[NE], te_tb[NE], te_tg[NE];
+    long long st_v = 0;
+    const bool want_table = ksplit <= 1;                        // split-K workgroups have no epilogue: no table
+    if (want_table) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = tid + e * HC_THREADS;
+            te_b[e] = 0.f; te_tb[e] = 0.f; te_tg[e] = 0.f;
+            if (i < 9 * TM) {
+                const int cls = i / TM, fl = i - cls * TM;
+                const int f = rowtile * TM + fl;
+                if (bias) te_b[e] = bias[f];
+                if (fold && f < p.nfeat) { te_tb[e] = p.Tb[(long long)cls * p.tab_ld + f]; te_tg[e] = p.Tg[(long long)cls * p.tab_ld + f]; }
+            }
         }
-        if (tid == 0) { scal[0] = mean; scal[1] = rstd; }
-        // Tc[cls][f] = bias + Tb[cls] - mean*rstd*Tg[cls] for this workgroup's TM features (read in phase 2)
-        const float mr = mean * rstd;
-        for (int i = tid; i < 9 * TM; i += HC_THREADS) {
-            const int cls = i / TM, fl = i - cls * TM;
-            const int f = rowtile * TM + fl;
-            float v = 0.f;
-            if (f < p.nfeat || bias) v = bias ? bias[f] : 0.f;
-            if (fold && f < p.nfeat) v += p.Tb[(long long)cls * p.tab_ld + f] - mr * p.Tg[(long long)cls * p.tab_ld + f];
-            tcs[i] = v;
+        if (fold && wave == 0 && lane < 2 * UCDIR_STAT_SLOTS) {  // lane l: slot l / 2, (sum | sum of squares) = l & 1
+            st_v = p.stats0[(long long)b * (2 * UCDIR_STAT_SLOTS) + lane];
+            if (p.stats1) st_v += p.stats1[(long long)b * (2 * UCDIR_STAT_SLOTS) + lane];
+        }
+    }
+    // second half of the prologue: called right behind the first DMA issue with this wave's DMA instruction count
+    auto build_table = [&](int ndma) {
+        hc_wait_vm(ndma);
+        if (wave == 0) {
+            float mean = 0.f, rstd = 1.f;
+            if (fold) {
+                long long v = st_v;                              // lanes of equal parity hold the 16 slots of one quantity
+#pragma unroll
+                for (int off = 2; off < 2 * UCDIR_STAT_SLOTS; off <<= 1) v += __shfl_xor(v, off);
+                const long long q = __shfl(v, 1);
+                mean_rstd(stat_val(v), stat_val(q), p.inv_count, mean, rstd);   // lane 0: v = sum, q = sum of squares
+            }
+            if (lane == 0) { scal[0] = mean; scal[1] = rstd; }
+        }
+        __syncthreads();
+        // Tc[cls][f] = bias + Tb[cls] - mean*rstd*Tg[cls] for this workgroup's TM features (read in the epilogue)
+        const float mr = scal[0] * scal[1];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = tid + e * HC_THREADS;
+            if (i < 9 * TM) tcs[i] = te_b[e] + te_tb[e] - mr * te_tg[e];
         }
     };
-    if (ksplit <= 1) build_table();
 
     // ---- halo loader geometry: instruction k = i*8 + wave stages halo pixels 16k .. 16k+15 ------
     int hsrc[3], hjsw[3];
@@ -226,6 +251,12 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     // ---- K loop: s = c*9 + t -------------------------------------------------------------------------
     issue_halo(cbeg, cbeg & 1);
     issue_A(cbeg, 0, 0);
+    if (want_table) {
+        int ndma = 2;                               // this wave's instructions in flight: two weight pieces + its halo pieces
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ndma += ((i * 8 + wave) * 16 < hcount) ? 1 : 0;
+        build_table(ndma);
+    }
     int c = cbeg, u = 0;                        // chunk and tap pair of the step being computed
     for (int s = 0; s < nk; ++s) {
         // everything older than the halo prefetch issued one step ago must have landed
