@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UCDIR_ABI_VERSION 2
+#define UCDIR_ABI_VERSION 3
 #define UCDIR_MAX_MULTS 8
 
 typedef struct ucdir_ctx ucdir_ctx;
@@ -121,7 +121,8 @@ int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
 /* Process-wide test switches, read when a shape is planned / an op entry point runs.
  * "flash": 1 = flash-attention kernel, 0 = materialised-score path (QK^T, softmax, PV as three launches),
  * -1 = environment default (UCDIR_NO_FLASH).  "splitk": 1 / 0 / -1 the same for split-K and unit splits of
- * under-filled grids (UCDIR_SPLITK).  Unknown names are an error. */
+ * under-filled grids (UCDIR_SPLITK).  "persist_grid": n > 0 launches the persistent kernels (akgm_ws) with n workgroups
+ * instead of one per compute unit, 0 restores the default.  Unknown names are an error. */
 int32_t ucdir_debug_flag(const char* name, int32_t value);
 /* Host-side launch planning, callable without a device (tests): what = "ksplit" -> the K-split factor conv3x3_halo would use
  * for a grid of `wgs` workgroups over `nchunks` 32-channel chunks of `steps_per_chunk` K steps producing `out_elems` outputs;
@@ -160,12 +161,13 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1,
                       int32_t cout, int32_t ksize, int32_t mode, int32_t silu,
                       const float* residual, float* y, double* stats_out_host, void* stream);
 /* AKGM block tail: y = swish(sum_s spdyconv(GN2(h))[c,s] * att[s]) + res
- * h: (B,C,H,W); att: (B,8,H,W) (= conv2(guide) * attw, already multiplied); res: (B,C,H,W) */
+ * h: (B,C,H,W); att: (B,8,H,W) (= conv2(guide) * attw, already multiplied); res: (B,C,H,W);
+ * stats_out_host (ABI 3, may be NULL): (B,2) doubles = the (sum, sum of squares) the launch accumulated for y. */
 int32_t ucdir_op_akgm(const float* h, const float* att, const float* res,
                       int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* wsp_host, const float* bsp_host,
                       const float* gamma_host, const float* beta_host,
-                      float* y, void* stream);
+                      float* y, double* stats_out_host, void* stream);
 /* SelfAttention.forward (model/ucdir.py:165-182): y = out(softmax(q^T k / sqrt(C)) v) + x */
 int32_t ucdir_op_attention(const float* x, int32_t B, int32_t C, int32_t H, int32_t W,
                            const float* gamma_host, const float* beta_host,

@@ -111,10 +111,17 @@ def akgm_case(B, C, H, W, seed=0):
     y = O.swish((hset * att.unsqueeze(1)).sum(2)) + res
     dy = torch.empty(B, C, H, W, device=DEV)
     dh, datt, dres = h.to(DEV), att.to(DEV), res.to(DEV)      # keep alive: raw pointers cross the ABI
+    stats = np.zeros((B, 2), dtype=np.float64)
     ulib.check(L.ucdir_op_akgm(_p(dh), _p(datt), _p(dres), B, C, H, W, _hp(wsp.numpy().copy()),
-                               _hp(bsp.numpy().copy()), _hp(gamma.numpy().copy()), _hp(beta.numpy().copy()), _p(dy), _st()))
+                               _hp(bsp.numpy().copy()), _hp(gamma.numpy().copy()), _hp(beta.numpy().copy()), _p(dy), _hp(stats), _st()))
     torch.cuda.synchronize()
     m = metrics(dy, y)
+    # (sum, sum of squares) the launch accumulated for its output vs float64 sums of the output it stored (bf16-rounded after
+    # the statistics were taken: the rounding noise averages out)
+    got = dy.double().cpu()
+    st_ref = np.stack([got.sum(dim=(1, 2, 3)).numpy(), got.pow(2).sum(dim=(1, 2, 3)).numpy()], 1)
+    m["stats_rel"] = float(np.abs(stats - st_ref).max() / np.abs(st_ref).max())
+    m["stats"] = stats.tolist()
     d = (dy.cpu() - y).abs()
     m["max_abs_border"] = float(torch.cat([d[..., 0, :].flatten(), d[..., -1, :].flatten(), d[..., :, 0].flatten(),
                                            d[..., :, -1].flatten()]).max())

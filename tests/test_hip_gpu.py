@@ -60,6 +60,28 @@ def test_akgm(Cc):
     assert m["max_abs_border"] < 0.06, m
 
 
+@pytest.mark.parametrize("args", [
+    (3, 64, 32, 48, 0),      # 16 x 16 tiles, every tile a border tile, one tile per workgroup
+    (3, 64, 64, 80, 7),      # persistent ranges of 8-9 tiles that cross sample boundaries (grid forced to 7 workgroups)
+    (2, 64, 40, 56, 3),      # ragged tiles (clamped halo, masked stores) inside multi-tile ranges
+    (2, 64, 288, 288, 0),    # the network's level-0 size: 648 tiles on one workgroup per CU
+], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0"])
+def test_akgm_persistent(args):
+    """akgm_ws_kernel (8 channels per group, persistent, weight-stationary): tile ranges, sample crossings, border classes."""
+    B, Cc, H, W, grid = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    try:
+        m = C.akgm_case(B, Cc, H, W, seed=5)
+        m2 = C.akgm_case(B, Cc, H, W, seed=5)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.06, m
+    assert m["stats_rel"] < 1e-3, m                                      # GroupNorm partial sums of the output
+    assert m["max_abs"] == m2["max_abs"] and m["rel_rms"] == m2["rel_rms"] and m["stats"] == m2["stats"]     # reproducible
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18)])
 @pytest.mark.parametrize("flash", [1, -1], ids=["flash", "engine_choice"])
 def test_attention(shape, flash):

@@ -31,7 +31,7 @@ elif kind == "akgm":
     gm = np.ones(Cc, np.float32); bt = np.zeros(Cc, np.float32)
     y = torch.empty(B, Cc, H, W, device="cuda")
     for _ in range(reps):
-        ulib.check(L.ucdir_op_akgm(C._p(h), C._p(att), C._p(res), B, Cc, H, W, C._hp(wsp), C._hp(bsp), C._hp(gm), C._hp(bt), C._p(y), C._st()))
+        ulib.check(L.ucdir_op_akgm(C._p(h), C._p(att), C._p(res), B, Cc, H, W, C._hp(wsp), C._hp(bsp), C._hp(gm), C._hp(bt), C._p(y), C._hp(None), C._st()))
     torch.cuda.synchronize()
     print("done", float(y.abs().mean()))
 elif kind == "attn":        # python tools/bench_op.py attn B C H W [reps]   (flash kernel forced; UCDIR_LIB=timing build prints the phase stamps)

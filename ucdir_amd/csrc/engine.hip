@@ -17,6 +17,7 @@
 #include "conv_halo.hip.h"
 #include "akgm_halo.hip.h"
 #include "akgm_pre.hip.h"
+#include "akgm_ws.hip.h"
 #include "flash_attn.hip.h"
 #include "common.h"
 #include "misc.hip.h"
@@ -171,6 +172,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv3x3_halo_kernel<64, true>, hc_lds_bytes<64>());
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
+    set_lds_attr(akgm_ws_kernel, AkWs::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -306,6 +308,22 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
 }
 
 static bool g_use_halo = true;
+
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+static int g_persist_grid = 0;      // > 0: ucdir_debug_flag("persist_grid", n) forces the grid of the persistent kernels (tests: many tiles per workgroup on small inputs)
+static int num_cus() {
+    if (g_persist_grid > 0) return g_persist_grid;
+    static std::map<int, int> memo;
+    int dev = 0;
+    HIPC(hipGetDevice(&dev));
+    auto it = memo.find(dev);
+    if (it != memo.end()) return it->second;
+    int n = 0;
+    HIPC(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n <= 0) n = 256;
+    memo[dev] = n;
+    return n;
+}
 
 // split-K scratch: raw fp32 partial tiles of at most SPLITK_MAX_WGS workgroups of 256 px x 128 rows (64 MiB), one per device, allocated with the kernel attributes (never on the launch path: forwards are captured into HIP graphs)
 static float* splitk_scratch() {
@@ -486,8 +504,42 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     p.dbg = nullptr;
     static const bool use_attlds = !getenv("UCDIR_NO_ATTLDS");
     const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
+    // persistent weight-stationary kernel (akgm_ws.hip.h): one workgroup per CU walks a range of tiles; UCDIR_NO_WS falls back
+    static const bool use_ws = !getenv("UCDIR_NO_WS");
+    const bool ws = pre && use_ws && w.C == 64;
     auto launch = [&]() {
-        if (pre) {
+        if (ws) {
+            const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
+            p.usplit = getenv("UCDIR_WS_DBG") ? atoi(getenv("UCDIR_WS_DBG")) : 0;
+            const int grid = ntiles < ncu ? ntiles : ncu;
+            static unsigned* wsdbg = nullptr;
+            if (p.usplit & 32) {
+                if (!wsdbg) HIPC(hipMalloc((void**)&wsdbg, 1024 * 4096));
+                HIPC(hipMemset(wsdbg, 0, 1024 * 4096));
+                p.dbg = (unsigned long long*)wsdbg;
+            }
+            hipLaunchKernelGGL(akgm_ws_kernel, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
+            if (p.usplit & 32) {
+                std::vector<unsigned> hd((size_t)grid * 1024);
+                HIPC(hipStreamSynchronize(st));
+                HIPC(hipMemcpy(hd.data(), wsdbg, hd.size() * 4, hipMemcpyDeviceToHost));
+                int nh = 0, na = 0, shown = 0;
+                for (int l = 0; l < grid; ++l) {
+                    const unsigned* d = hd.data() + (size_t)l * 1024;
+                    int dh = 0, da = 0;
+                    for (int i = 0; i < 256; ++i) { dh += d[i] != d[256 + i]; da += d[512 + i] != d[768 + i]; }
+                    if (dh) ++nh; if (da) ++na;
+                    if ((dh || da) && shown < 3) {
+                        ++shown;
+                        fprintf(stderr, "WSDBG lid %d tile %u buf %u t_beg %u: halo words differing %d, att words differing %d\n", l, d[1020], d[1021], d[1022], dh, da);
+                        fprintf(stderr, "   halo early:"); for (int i = 0; i < 12; ++i) fprintf(stderr, " %08x", d[i]); fprintf(stderr, "\n   halo late :"); for (int i = 0; i < 12; ++i) fprintf(stderr, " %08x", d[256 + i]);
+                        fprintf(stderr, "\n   att  early:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", ((const float*)d)[512 + i]); fprintf(stderr, "\n   att  late :"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", ((const float*)d)[768 + i]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+                fprintf(stderr, "WSDBG %d of %d workgroups: halo changed during the last tile; %d: att changed\n", nh, grid, na);
+            }
+        } else if (pre) {
             hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
         } else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
         else hipLaunchKernelGGL(akgm_halo_stage_kernel, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
@@ -1284,6 +1336,7 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     require(name != nullptr, "null argument");
     if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
+    else if (!strcmp(name, "persist_grid")) g_persist_grid = value;   // persistent kernels: workgroups per launch (0 = one per CU)
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END
 }
@@ -1377,7 +1430,7 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
 
 int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* wsp_host, const float* bsp_host, const float* gamma_host, const float* beta_host,
-                      float* y, void* stream) {
+                      float* y, double* stats_out_host, void* stream) {
     API_BEGIN
     ensure_kernel_attrs();
     hipStream_t st = (hipStream_t)stream;
@@ -1394,7 +1447,16 @@ int32_t ucdir_op_akgm(const float* h, const float* att, const float* res, int32_
     run_akgm(w, ah, G, attw, ar, out, tcbuf, st);
     hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, C, H, W);
     HIPC(hipGetLastError());
+    std::vector<stat_t> sfx;
+    if (stats_out_host) { sfx.resize((size_t)2 * UCDIR_STAT_SLOTS * B); HIPC(hipMemcpyAsync(sfx.data(), out.stats, sizeof(stat_t) * sfx.size(), hipMemcpyDeviceToHost, st)); }
     HIPC(hipStreamSynchronize(st));
+    if (stats_out_host)
+        for (int bb = 0; bb < B; ++bb)
+            for (int q = 0; q < 2; ++q) {                   // fixed-point slots -> (sum, sum of squares)
+                stat_t acc = 0;
+                for (int k = 0; k < UCDIR_STAT_SLOTS; ++k) acc += sfx[((size_t)bb * UCDIR_STAT_SLOTS + k) * 2 + q];
+                stats_out_host[bb * 2 + q] = (double)acc / UCDIR_STAT_SCALE;
+            }
     API_END
 }
 
