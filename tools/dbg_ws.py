@@ -24,7 +24,8 @@ hn = F.group_norm(h, 1, gamma, beta, eps=1e-5)
 hset = F.conv2d(hn, wsp, bsp, padding=1, groups=8).view(B, Cc, 8, H, W)
 y = O.swish((hset * att.unsqueeze(1)).sum(2)) + res
 ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
-for rep in range(3):
+first = None
+for rep in range(int(os.environ.get('DBG_REPS', '3'))):
     dy = torch.full((B, Cc, H, W), 7.0, device="cuda")
     dh, datt, dres = h.cuda(), att.cuda(), res.cuda()
     st = np.zeros((B, 2))
@@ -33,7 +34,9 @@ for rep in range(3):
     torch.cuda.synchronize()
     d = (dy.cpu() - y)
     bad = (~torch.isfinite(d)) | (d.abs() > 0.05)
-    print("rep", rep, "bad elements", int(bad.sum()), "of", bad.numel(), "nan", int(torch.isnan(dy).sum()))
+    if first is None: first = dy.clone()
+    if not torch.equal(first, dy): print("rep", rep, "NOT bit-identical to rep 0:", int((first != dy).sum()), "elements")
+    if rep < 3 or bad.any(): print("rep", rep, "bad elements", int(bad.sum()), "of", bad.numel(), "nan", int(torch.isnan(dy).sum()))
     if bad.any():
         idx = bad.nonzero()
         bs, cs, ys, xs = idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]

@@ -506,39 +506,12 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
     // persistent weight-stationary kernel (akgm_ws.hip.h): one workgroup per CU walks a range of tiles; UCDIR_NO_WS falls back
     static const bool use_ws = !getenv("UCDIR_NO_WS");
-    const bool ws = pre && use_ws && w.C == 64;
+    const bool ws = pre && use_ws && w.C == 64 && y.H % 16 == 0 && y.W % 16 == 0 && p.th == 16 && p.tw == 16;
     auto launch = [&]() {
         if (ws) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
-            p.usplit = getenv("UCDIR_WS_DBG") ? atoi(getenv("UCDIR_WS_DBG")) : 0;
             const int grid = ntiles < ncu ? ntiles : ncu;
-            static unsigned* wsdbg = nullptr;
-            if (p.usplit & 32) {
-                if (!wsdbg) HIPC(hipMalloc((void**)&wsdbg, 1024 * 4096));
-                HIPC(hipMemset(wsdbg, 0, 1024 * 4096));
-                p.dbg = (unsigned long long*)wsdbg;
-            }
             hipLaunchKernelGGL(akgm_ws_kernel, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
-            if (p.usplit & 32) {
-                std::vector<unsigned> hd((size_t)grid * 1024);
-                HIPC(hipStreamSynchronize(st));
-                HIPC(hipMemcpy(hd.data(), wsdbg, hd.size() * 4, hipMemcpyDeviceToHost));
-                int nh = 0, na = 0, shown = 0;
-                for (int l = 0; l < grid; ++l) {
-                    const unsigned* d = hd.data() + (size_t)l * 1024;
-                    int dh = 0, da = 0;
-                    for (int i = 0; i < 256; ++i) { dh += d[i] != d[256 + i]; da += d[512 + i] != d[768 + i]; }
-                    if (dh) ++nh; if (da) ++na;
-                    if ((dh || da) && shown < 3) {
-                        ++shown;
-                        fprintf(stderr, "WSDBG lid %d tile %u buf %u t_beg %u: halo words differing %d, att words differing %d\n", l, d[1020], d[1021], d[1022], dh, da);
-                        fprintf(stderr, "   halo early:"); for (int i = 0; i < 12; ++i) fprintf(stderr, " %08x", d[i]); fprintf(stderr, "\n   halo late :"); for (int i = 0; i < 12; ++i) fprintf(stderr, " %08x", d[256 + i]);
-                        fprintf(stderr, "\n   att  early:"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", ((const float*)d)[512 + i]); fprintf(stderr, "\n   att  late :"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", ((const float*)d)[768 + i]);
-                        fprintf(stderr, "\n");
-                    }
-                }
-                fprintf(stderr, "WSDBG %d of %d workgroups: halo changed during the last tile; %d: att changed\n", nh, grid, na);
-            }
         } else if (pre) {
             hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
         } else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
