@@ -53,6 +53,26 @@ def test_conv_gemm(args):
     assert m["stats_rel"] < 1e-3, m                                    # GroupNorm partial sums
 
 
+@pytest.mark.parametrize("args", [
+    (3, 32, 48, True, True, 0),       # 16 x 16 tiles, all border tiles, one tile per workgroup; GroupNorm fold + swish
+    (3, 64, 80, True, True, 7),       # persistent ranges of 8-9 tiles crossing sample boundaries (grid forced to 7 workgroups)
+    (2, 48, 48, False, False, 5),     # no fold, no activation (bias only)
+    (2, 288, 288, True, True, 0),     # the network's level-0 size on one workgroup per CU
+], ids=["even_small", "ranges_cross_samples", "plain", "level0"])
+def test_conv_persistent(args):
+    """conv_ws_kernel (3x3, 64 -> 64, persistent, weights in registers): tile ranges, sample crossings, border classes, stats."""
+    B, H, W, gn, silu, grid = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    try:
+        m = C.conv_case(B, H, W, 64, 0, 64, 3, 0, gn, silu, False, seed=3)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m
+    assert m["stats_rel"] < 1e-3, m
+
+
 @pytest.mark.parametrize("Cc", [64, 128, 256, 512])
 def test_akgm(Cc):
     m = C.akgm_case(2, Cc, 20, 24)

@@ -18,6 +18,7 @@
 #include "akgm_halo.hip.h"
 #include "akgm_pre.hip.h"
 #include "akgm_ws.hip.h"
+#include "conv_ws.hip.h"
 #include "flash_attn.hip.h"
 #include "common.h"
 #include "misc.hip.h"
@@ -94,6 +95,7 @@ struct ConvW {
     int rows_pad = 0, Kpad = 0, ntaps = 0, cin = 0, cout = 0, TM = 128; bool fold = false;
     bf16_t* Aup = nullptr; int Kup = 0;     // Upsample convs: parity-decomposed 2x2 weights [4][rows_pad][4*cin]
     bf16_t* A10 = nullptr; float* bias_res = nullptr;   // conv1 + the block's res_conv as a 10th tap (64-row tiles only)
+    bf16_t* Aws = nullptr;                               // 3x3 64 -> 64: A fragments of the persistent weight-stationary kernel (conv_ws.hip.h)
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -112,6 +114,7 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     W.fold = gamma != nullptr;
     if (W.fold) { W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg); }
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
+    if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
     return W;
 }
 static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
@@ -173,6 +176,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel, AkWs::LDS);
+    set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -453,6 +457,27 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         p.alt_A = wres->A; p.alt_a_ld = wres->Kpad; p.bias2 = wres->bias;
         p.out2 = res_out->p; p.out2_bstride = res_out->bstride(); p.out2_ld = res_out->C;
         did_res = true;
+    }
+    // 64 -> 64 on 16 x 16 tiles: persistent weight-stationary kernel (conv_ws.hip.h); UCDIR_NO_CONV_WS falls back
+    static const bool use_cws = !getenv("UCDIR_NO_CONV_WS");
+    if (use_cws && halo && !upph && !did_res && !dual && w.Aws && !x1 && !res && !p.out_nchw && p.ksplit <= 1 && !p.alt_blocks &&
+        y.H % 16 == 0 && y.W % 16 == 0 && x0.C == 64 && y.C == 64) {
+        p.A = w.Aws; p.th = 16; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 16;
+        const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
+        const int grid = ntiles < ncu ? ntiles : ncu;
+        if (g_prof.on) {
+            ProfEntry e; e.key = 21; gemm_work(p, EPI_STD, e.flops, e.bytes);
+            e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
+            e.e0 = g_prof.get(); e.e1 = g_prof.get();
+            HIPC(hipEventRecord(e.e0, st));
+            hipLaunchKernelGGL(conv_ws_kernel, dim3(grid), dim3(HC_THREADS), CvWs::LDS, st, p);
+            HIPC(hipEventRecord(e.e1, st));
+            g_prof.entries.push_back(e);
+        } else {
+            hipLaunchKernelGGL(conv_ws_kernel, dim3(grid), dim3(HC_THREADS), CvWs::LDS, st, p);
+        }
+        HIPC(hipGetLastError());
+        return did_res;
     }
     if (halo) { if (tm_run == 128) launch_halo<128>(p, st); else if (dual) launch_halo<64, true>(p, st); else launch_halo<64>(p, st); }
     else launch_cgemm(p, w.TM, EPI_STD, st);

@@ -73,6 +73,25 @@ static inline PackedConv pack_conv(const float* w, const float* bias, const floa
     return P;
 }
 
+// conv_ws_kernel (conv_ws.hip.h), 3x3 conv 64 -> 64: A fragments as the waves load them, [rw][step j][hh][32 rows][8] bf16 with
+// j = 4 tap + c16 (input channels 16 c16 + 8 hh .. + 7) and MFMA row rho of row tile rw <-> output channel
+// 32 rw + 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3): in the 32x32 accumulator layout (row = (reg & 3) + 8 (reg >> 2) + 4 hh)
+// register r of lane half hh is then channel 32 rw + 16 hh + r - 16 consecutive channels per lane.
+// P: pack_conv(...) of the same layer with Kpad == 9 * 64 (GroupNorm gamma already folded in).
+static inline std::vector<bf16_t> pack_conv_ws(const PackedConv& P) {
+    std::vector<bf16_t> img((size_t)2 * 36 * 2 * 32 * 8, 0);
+    for (int rw = 0; rw < 2; ++rw)
+        for (int j = 0; j < 36; ++j)
+            for (int hk = 0; hk < 2; ++hk)
+                for (int rho = 0; rho < 32; ++rho) {
+                    const int o = 32 * rw + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+                    const int tap = j >> 2, c0 = 16 * (j & 3) + 8 * hk;
+                    for (int e = 0; e < 8; ++e)
+                        img[((((size_t)rw * 36 + j) * 2 + hk) * 32 + rho) * 8 + e] = P.A[(size_t)o * P.Kpad + (size_t)tap * 64 + c0 + e];
+                }
+    return img;
+}
+
 // conv1 of a residual block whose res_conv is fused into it (conv3x3_halo_kernel<64>): the packed rows get a 10th
 // tap block holding the 1x1 res_conv weights (plain bf16, no GroupNorm fold: res_conv sees the raw input).
 // P: pack_conv(conv1) with Kpad == 9*cin; wres: [cout][cin].  Returns [rows_pad][10*cin].
