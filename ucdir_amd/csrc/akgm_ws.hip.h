@@ -65,7 +65,7 @@ __device__ __forceinline__ u32x4_t asm_load16(const void* base, unsigned voff) {
 #define WS_WAIT_RES(N, v) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); asm volatile("" : "+v"(v) :: "memory"); } while (0)
 
 #ifndef WS_PK
-#define WS_PK 1                                                   // modulation sum on v_pk_fma_f32 (half the issue slots)
+#define WS_PK 0                                                   // 1: modulation sum on v_pk_fma_f32 - half the issue slots, but measured 2 % SLOWER (same box, 198 vs 194 us): packed fp32 beside the partner wave's MFMAs is an anti-lever (cdna guide, price list)
 #endif
 
 __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) {
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = group
     const int U = wave >> 1, wm = wave & 1;                       // unit / row half of pack_akgm_pre
+    // lane -> pixel of a 32-pixel MFMA tile (two tile rows): row l31 / 16, column (l31 % 16) ^ 8 in the second row: with the
+    // 24-pixel pitch every ds_read_b128 lane group then reads 16 different 16-byte slots (the plain mapping was 2-way everywhere)
+    const int prow = l31 >> 4, pcol = (l31 & 15) ^ (prow << 3);
     int lid;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -124,12 +127,12 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int t = (2 * j + hh > 8) ? 8 : 2 * j + hh;               // tap 2j (lanes 0-31) | 2j + 1 (lanes 32-63; tap 9 has zero weights: reads tap 8)
-        const int hp = ((l31 >> 4) + t / 3) * AkWs::PITCH + (l31 & 15) + t % 3;
+        const int hp = (prow + t / 3) * AkWs::PITCH + pcol + t % 3;
         bj0[j] = (hp << 7) | ((wave ^ ((hp >> 1) & 7)) << 4);
     }
     const unsigned tc_lane = AkWs::OFF_TCS + 4 * 8 * (16 * U + 8 * wm + 2 * hh);   // + 128 tm + 2048 cls: first of this lane's 16 table entries
-    const unsigned att_lane = AkWs::OFF_ATT + l31 * 32;                            // + 1024 q: this lane's pixel of px-tile q
-    const unsigned rel2 = (unsigned)((((lane >> 4) + 1) * p.Wp + (lane & 15) + 1) * 64 + wave * 8) * 2;   // store item: pixel (lane / 16 + 4 pp, lane % 16), features 8 g ..
+    const unsigned att_lane = AkWs::OFF_ATT + (prow * 16 + pcol) * 32;              // + 1024 q: this lane's pixel of px-tile q
+    const unsigned rel2 = (unsigned)((((lane >> 4) + 1) * p.Wp + ((lane & 15) ^ (((lane >> 4) & 1) << 3)) + 1) * 64 + wave * 8) * 2;   // store item: pixel row lane / 16 + 4 pp, column as pcol, features 8 g ..
     const long long pp_step = (long long)4 * p.Wp * 64 * 2;            // bytes between the store items of consecutive pairs
 
     int b, ty, tx;                                 // tile t
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             for (int tp = 0; tp < 2; ++tp) {
                 unsigned tca = tc_lane + 4 * 2048;                  // class 4
                 if (!interior) {
-                    const int r = 4 * pp + 2 * tp + (l31 >> 4), c = l31 & 15;
+                    const int r = 4 * pp + 2 * tp + prow, c = pcol;
                     const int cy = (ty == 0 && r == 0) ? 0 : ((ty + 1 == p.tiles_y && r == 15) ? 2 : 1);
                     const int cx = (tx == 0 && c == 0) ? 0 : ((tx + 1 == p.tiles_x && c == 15) ? 2 : 1);
                     tca = tc_lane + (cy * 3 + cx) * 2048;

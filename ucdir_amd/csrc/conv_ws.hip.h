@@ -18,7 +18,12 @@
 //   * fold table Tc[9][64] of the current sample in LDS (rebuilt when the range crosses a sample); output statistics as
 //     fixed-point per-tile partials in 64-bit integers (partition-independent, see akgm_ws.hip.h).
 #pragma once
+#include <type_traits>
 #include "akgm_ws.hip.h"
+
+#ifndef CW_DEPTH
+#define CW_DEPTH 1                                                // B fragment reads issued this many K steps ahead of their MFMAs
+#endif
 
 struct CvWs {
     static constexpr int PITCH = AkWs::PITCH, HALO = AkWs::HALO, QSTEP = AkWs::QSTEP;
@@ -35,12 +40,25 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rw = wave & 1, pw = wave >> 1;
+    // lane -> pixel of a 32-pixel MFMA tile (two tile rows): row l31 / 16, column (l31 % 16) ^ 8 in the second row.  With the 24-pixel
+    // pitch the 16 lanes of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) then hit 16 different
+    // 16-byte slots (halo pixel index distinct mod 16); the plain mapping was 2-way on every read (PMC: conflicts 47 % of LDS cycles)
+    const int prow = l31 >> 4, pcol = (l31 & 15) ^ (prow << 3);
     int lid;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 1 || wave == 5);
+    unsigned long long* const dbgp = p.dbg + (wave == 5 ? 256 : 0);
+    int dbg_n = 0;
+#define CW_STAMP() do { if (dbg_on && dbg_n < 250) dbgp[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CW_STAMP() do {} while (0)
+#endif
+    CW_STAMP();
     const int tps = p.tiles_x * p.tiles_y;
     const int T = p.nbatch * tps;
     const int t_beg = (int)((long long)lid * T / (int)gridDim.x), t_end = (int)((long long)(lid + 1) * T / (int)gridDim.x);
@@ -57,29 +75,36 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
     for (int j = 0; j < 36; ++j) asm volatile("" : "+v"(af[j]));    // the wait for these loads goes here, not into the tile loop
 
     // ---- tile-invariant lane constants (halo staging as in akgm_ws.hip.h) ---------------------------------------------------
-    int hrel[7];
+    // Halo staging: piece (r, c3) = row r, pixel columns 8 c3 .. 8 c3 + 7 (columns >= 18 do not exist) goes to LDS bytes
+    // (3 r + c3) * 1024.  Wave w stages rows w and w + 8 (the per-lane source offset of row r + 8 is that of row r plus a
+    // wave-uniform 8 rows: the swizzle (hp >> 1) & 7 is the same), waves 2-7 one piece of rows 16 / 17 each: 4 offset registers.
+    int hrel[3], hrel_x = -1;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        int k = i * 8 + wave; k = k > 53 ? 53 : k;
-        const int r = k / 3, col = (k - 3 * r) * 8 + (lane >> 3);
-        const int hp = r * CvWs::PITCH + col;
-        hrel[i] = col < 18 ? (r * p.Wp + col) * 64 + (((lane & 7) ^ ((hp >> 1) & 7)) << 3) : -1;
+    for (int c3 = 0; c3 < 3; ++c3) {
+        const int col = c3 * 8 + (lane >> 3), hp = wave * CvWs::PITCH + col;
+        hrel[c3] = col < 18 ? (wave * p.Wp + col) * 64 + (((lane & 7) ^ ((hp >> 1) & 7)) << 3) : -1;
+    }
+    const int xr = 16 + (wave - 2) / 3, xc3 = (wave - 2) % 3;      // waves 2-7: the extra piece
+    if (wave >= 2) {
+        const int col = xc3 * 8 + (lane >> 3), hp = xr * CvWs::PITCH + col;
+        hrel_x = col < 18 ? (xr * p.Wp + col) * 64 + (((lane & 7) ^ ((hp >> 1) & 7)) << 3) : -1;
     }
     // B fragment of tap (ky, kx), chunk pair c16, pixel tile 2 pw (+ QSTEP: 2 pw + 1): halo pixel hp = hp0 + 24 ky + kx,
     // 16-byte chunk (2 c16 + hh) ^ ((hp >> 1) & 7).  (hp + 24) >> 1 adds 12: the swizzle flips bit 2 for ky = 1 and is
-    // unchanged for ky = 2, so with K = 2 c16 ^ (ky == 1 ? 4 : 0) in {0, 2, 4, 6} the address is  ba0[kx][K / 2] + 3072 ky.
-    unsigned ba0[3][4];
+    // unchanged for ky = 2, so with K = 2 c16 ^ (ky == 1 ? 4 : 0) in {0, 2, 4, 6} the address is  ba[kx][K / 2] + 3072 ky:
+    // twelve registers, no address arithmetic in the K loop (the kernel is bound by instruction ISSUE: ~4.5 cycles per instruction and SIMD).
+    unsigned ba[3][4];                             // [kx][K / 2]: LDS byte address of the fragment (buffer 0; flipped in place every tile)
     {
-        const int hp0 = (4 * pw + (l31 >> 4)) * CvWs::PITCH + (l31 & 15);
+        const int hp0 = (4 * pw + prow) * CvWs::PITCH + pcol;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int sxh = (((hp0 + kx) >> 1) & 7) ^ hh;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) ba0[kx][k2] = ((hp0 + kx) << 7) + (((2 * k2) ^ sxh) << 4);
+            for (int k2 = 0; k2 < 4; ++k2) ba[kx][k2] = ((hp0 + kx) << 7) + (((2 * k2) ^ sxh) << 4);
         }
     }
     const unsigned tc_lane = CvWs::OFF_TCS + (32 * rw + 16 * hh) * 4;              // + 256 cls: this lane's 16 channels of the fold table
-    const unsigned rel_out = (unsigned)(((4 * pw + (l31 >> 4) + 1) * p.Wp + (l31 & 15) + 1) * 64 + 32 * rw + 16 * hh) * 2;   // pixel tile 2 pw; + 2 Wp rows: 2 pw + 1
+    const unsigned rel_out = (unsigned)(((4 * pw + prow + 1) * p.Wp + pcol + 1) * 64 + 32 * rw + 16 * hh) * 2;   // pixel tile 2 pw; + 2 Wp rows: 2 pw + 1
 
     int b, ty, tx;
     {
@@ -91,10 +116,12 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
         const bf16_t* hb = p.B0 + (long long)nb * p.b0_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * 64;
         unsigned char* hd = smem + buf * CvWs::HALO;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            int k = i * 8 + wave; k = k > 53 ? 53 : k;
-            if (hrel[i] >= 0) stage16(hb + hrel[i], hd + k * 1024, lane);
-        }
+        for (int c3 = 0; c3 < 3; ++c3)
+            if (hrel[c3] >= 0) {
+                stage16(hb + hrel[c3], hd + (3 * wave + c3) * 1024, lane);
+                stage16(hb + (long long)8 * p.Wp * 64 + hrel[c3], hd + (3 * (wave + 8) + c3) * 1024, lane);
+            }
+        if (wave >= 2) { if (hrel_x >= 0) stage16(hb + hrel_x, hd + (3 * xr + xc3) * 1024, lane); }
     };
     issue_tile(b, ty, tx, 0);
 
@@ -103,13 +130,72 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
     stat_t S1 = 0, S2 = 0;
     const int act = p.act;
 
+    // The two waves of a SIMD (w and w + 4) run STAGGERED by half a tile: waves 4-7 ("late") keep the accumulators of tile t
+    // across the barrier and run its epilogue at the top of tile t + 1, i.e. while waves 0-3 are in their K loop - and are in
+    // their own K loop while waves 0-3 run their epilogue.  In lockstep (one barrier per tile aligns all eight waves) both
+    // waves of a SIMD wanted the matrix pipe at the same time and the VALU at the same time: MFMA busy 39 %.
+    f32x16_t acc[2];
+    bool pend = false;                                              // late waves: epilogue of tile (pb, pty, ptx) not yet run
+    int pb = 0, pty = 0, ptx = 0;
+    // ---- epilogue in registers: lane = pixel (prow, pcol) of the pixel tile, channels 32 rw + 16 hh .. + 15 -----------------
+    // wait_dma: the early waves pass their vmcnt(0) between the arithmetic and the stores (see the tile loop)
+    auto epilogue = [&](int eb, int ety, int etx, const bool wait_dma) {
+        const bool interior = ety > 0 && etx > 0 && ety + 1 < p.tiles_y && etx + 1 < p.tiles_x;
+        unsigned char* outb = reinterpret_cast<unsigned char*>(reinterpret_cast<bf16_t*>(p.out) + (long long)eb * p.out_bstride + (long long)(ety * 16 * p.Wp + etx * 16) * 64);
+        float s1 = 0.f, s2 = 0.f;
+        uint4 pk[2][2];
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            unsigned tca = tc_lane + 4 * 256;                       // class 4
+            if (!interior) {
+                const int r = 4 * pw + 2 * tp + prow, c = pcol;
+                const int cy = (ety == 0 && r == 0) ? 0 : ((ety + 1 == p.tiles_y && r == 15) ? 2 : 1);
+                const int cx = (etx == 0 && c == 0) ? 0 : ((etx + 1 == p.tiles_x && c == 15) ? 2 : 1);
+                tca = tc_lane + (cy * 3 + cx) * 256;
+            }
+            // (scalar fp32 on purpose: the same arithmetic on v_pk_fma / v_pk_mul / v_pk_add_f32 - half the issue slots - ran the
+            // epilogue at 4.8 k instead of 3.3 k cycles beside the partner wave's MFMAs: 105 -> 130 us per launch)
+            float v[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 16 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g4 + e] = fmaf(acc[tp][4 * g4 + e], rstd_a, c4[e]);
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = silu_fast(v[i]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+            pk[tp][0] = pack8_bf16(v); pk[tp][1] = pack8_bf16(v + 8);
+        }
+        if (wait_dma) { HC_WAIT(0); }
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            unsigned char* op = outb + rel_out + (long long)tp * (2 * p.Wp * 64 * 2);
+            *reinterpret_cast<uint4*>(op) = pk[tp][0];
+            *reinterpret_cast<uint4*>(op + 16) = pk[tp][1];
+        }
+        S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
+    };
+
+    // two specialised copies of the tile loop (a wave-uniform flag in ONE loop made hipcc carry both liveness patterns: 48 spills)
+    auto tile_loop = [&](auto late_tag) {
+    constexpr bool late = decltype(late_tag)::value;
 #pragma unroll 1
     for (int t = t_beg; t < t_end; ++t) {
         const int buf = (t - t_beg) & 1;
         const bool last = t + 1 == t_end;
-        // every wave drained its VMEM queue at the end of the tile before (its DMA pieces of this tile included)
+        // every wave passed vmcnt(0) behind the K loop of the tile before (its DMA pieces of this tile included)
+        CW_STAMP();                                                 // tile top
         if (t == t_beg) { HC_WAIT(0); }
         asm volatile("s_barrier" ::: "memory");
+        CW_STAMP();                                                 // behind the barrier
+        if (late && pend) { epilogue(pb, pty, ptx, false); pend = false; }  // late waves: tile t - 1, under the early waves' K loop (and in front of a table rebuild)
         if (b != b_cur) {                                           // range enters a new sample: statistics -> fold table
             if (b_cur >= 0 && p.stats_out) {
                 const stat_t a = wave_sum_ll(S1), q2 = wave_sum_ll(S2);
@@ -142,25 +228,26 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
         }
         int nb = b, nty = ty, ntx = tx + 1;                          // tile t + 1
         if (ntx == p.tiles_x) { ntx = 0; if (++nty == p.tiles_y) { nty = 0; ++nb; } }
+        CW_STAMP();                                                 // (late waves: epilogue of tile t - 1 done)
         if (!last) issue_tile(nb, nty, ntx, buf ^ 1);
+        CW_STAMP();                                                 // DMA of tile t + 1 issued
 
-        const unsigned bufh = buf * CvWs::HALO;
-        unsigned ba[3][4];
+        if (t != t_beg) {                                           // the fragment addresses follow the halo buffer
+            const int d = buf ? CvWs::HALO : -CvWs::HALO;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) ba[kx][k2] = ba0[kx][k2] + bufh;
-
+                for (int k2 = 0; k2 < 4; ++k2) ba[kx][k2] += d;
+        }
         // ---- K loop: 9 taps x 4 chunk pairs, two pixel tiles share every A fragment -------------------------------------
-        f32x16_t acc[2];
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[tp][e] = 0.f;
         __builtin_amdgcn_s_setprio(1);
-        // software pipeline, depth one: the two fragment reads of step j + 1 are issued in front of the two MFMAs of step j
+        // software pipeline: the two fragment reads of step j + CW_DEPTH are issued in front of the two MFMAs of step j
         // (order pinned with sched_group_barrier: left alone, hipcc hoists dozens of reads and spills 67 registers)
-        bf16x8_t bq[2][2];
+        bf16x8_t bq[CW_DEPTH + 1][2];
         auto read_b = [&](int j, int slot) {
             const int tap = j >> 2, c16 = j & 3;
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -170,57 +257,38 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
             bq[slot][1] = *reinterpret_cast<const bf16x8_t*>(smem + a0 + CvWs::QSTEP);
         };
         __builtin_amdgcn_sched_barrier(0);
-        read_b(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int j = 0; j < CW_DEPTH; ++j) read_b(j, j);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * CW_DEPTH, 0);
 #pragma unroll
         for (int j = 0; j < 36; ++j) {
-            if (j + 1 < 36) read_b(j + 1, (j + 1) & 1);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j & 1][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j & 1][1], acc[1], 0, 0, 0);
-            if (j + 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (j + CW_DEPTH < 36) read_b(j + CW_DEPTH, (j + CW_DEPTH) % (CW_DEPTH + 1));
+            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // step 0: C = 0 as an inline constant
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % (CW_DEPTH + 1)][0], j ? acc[0] : zero, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % (CW_DEPTH + 1)][1], j ? acc[1] : zero, 0, 0, 0);
+            if (j + CW_DEPTH < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
-
-        // ---- epilogue in registers: lane = pixel l31 of the pixel tile, channels 32 rw + 16 hh .. + 15 ----------------------
-        const bool interior = ty > 0 && tx > 0 && ty + 1 < p.tiles_y && tx + 1 < p.tiles_x;
-        unsigned char* outb = reinterpret_cast<unsigned char*>(reinterpret_cast<bf16_t*>(p.out) + (long long)b * p.out_bstride + (long long)(ty * 16 * p.Wp + tx * 16) * 64);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-            unsigned tca = tc_lane + 4 * 256;                       // class 4
-            if (!interior) {
-                const int r = 4 * pw + 2 * tp + (l31 >> 4), c = l31 & 15;
-                const int cy = (ty == 0 && r == 0) ? 0 : ((ty + 1 == p.tiles_y && r == 15) ? 2 : 1);
-                const int cx = (tx == 0 && c == 0) ? 0 : ((tx + 1 == p.tiles_x && c == 15) ? 2 : 1);
-                tca = tc_lane + (cy * 3 + cx) * 256;
-            }
-            float v[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 16 * g4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g4 + e] = fmaf(acc[tp][4 * g4 + e], rstd_a, c4[e]);
-            }
-            if (act == 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = silu_fast(v[i]);
-            } else if (act == 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
-            unsigned char* op = outb + rel_out + (long long)tp * (2 * p.Wp * 64 * 2);
-            *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
-            *reinterpret_cast<uint4*>(op + 16) = pack8_bf16(v + 8);
-        }
-        S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
-        // this wave's DMA pieces of tile t + 1 must be in LDS before it reaches the next barrier (its own four stores ride along)
-        HC_WAIT(0);
+        CW_STAMP();                                                 // K loop done
+        // This wave's DMA pieces of tile t + 1 must be in LDS before it reaches the next barrier, and an LDS-DMA fill runs at
+        // ~12 bytes per cycle and CU: the 54 KB of a tile need ~5 k cycles from issue.  Late waves (DMA issued behind their
+        // epilogue at the top, stores long retired) wait here, behind the K loop; early waves wait between the arithmetic of
+        // their epilogue and its four stores - waiting in front of it cost them 1.5 k cycles per tile, waiting behind the
+        // stores would wait for the stores.
+        if (late) { HC_WAIT(0); }
+        CW_STAMP();                                                 // (late waves: vmcnt(0) passed)
+        if (late) { pend = true; pb = b; pty = ty; ptx = tx; } else epilogue(b, ty, tx, true);
+        CW_STAMP();                                                 // (early waves: epilogue done)
         b = nb; ty = nty; tx = ntx;
     }
+    if (late && pend) epilogue(pb, pty, ptx, false);
+#ifdef UCDIR_TIMING
+    if (dbg_on) dbgp[255] = dbg_n;
+#endif
+    };
+    if (wave >= 4) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
     if (p.stats_out) {
         const stat_t a = wave_sum_ll(S1), q2 = wave_sum_ll(S2);
         if (lane == 0) stat_add_fx(p.stats_out, b_cur, a, q2);

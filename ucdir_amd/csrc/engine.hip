@@ -465,8 +465,27 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         p.A = w.Aws; p.th = 16; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 16;
         const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
         const int grid = ntiles < ncu ? ntiles : ncu;
+#ifdef UCDIR_TIMING
+        {
+            static unsigned long long* dbgbuf = nullptr;
+            if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 512 * 8));
+            HIPC(hipMemset(dbgbuf, 0, 512 * 8));
+            p.dbg = dbgbuf;
+            hipLaunchKernelGGL(conv_ws_kernel, dim3(grid), dim3(HC_THREADS), CvWs::LDS, st, p);
+            unsigned long long h[512];
+            HIPC(hipStreamSynchronize(st));
+            HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 2; ++w) {
+                const int n = (int)h[w * 256 + 255];
+                fprintf(stderr, "CONV_WS TIMING %s n=%d:", w ? "late" : "early", n);
+                for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[w * 256 + i] - h[w * 256 + i - 1]);
+                fprintf(stderr, "\n");
+            }
+            return did_res;
+        }
+#endif
         if (g_prof.on) {
-            ProfEntry e; e.key = 21; gemm_work(p, EPI_STD, e.flops, e.bytes);
+            ProfEntry e; e.key = 23; gemm_work(p, EPI_STD, e.flops, e.bytes);
             e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
             e.e0 = g_prof.get(); e.e1 = g_prof.get();
             HIPC(hipEventRecord(e.e0, st));
@@ -559,7 +578,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = pre ? 112 : 111; e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        ProfEntry e; e.key = ws ? 113 : (pre ? 112 : 111); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
         e.dH = y.H; e.dW = y.W; e.dCin = w.C; e.dCout = w.C;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
