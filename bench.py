@@ -268,6 +268,7 @@ def patch_mode(args, net, dev, dist, rank, world, T):
     if dist is not None:
         net.denoise_fn.patch_group = dist.group.WORLD
     net.noise_seed = 1234                                     # every rank applies the identical sampler update
+    net.denoise_fn.patch_timers = [] if dist is not None else None    # (start, end) events of every all-gather
     if args.patch_batch:
         net.denoise_fn.patch_max_batch = args.patch_batch
     cond = torch.from_numpy(synth_inputs(1, H, W, seed=0)[0]).to(dev)
@@ -314,6 +315,15 @@ def patch_mode(args, net, dev, dist, rank, world, T):
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert torch.isfinite(out).all()
+    # self-explaining scaling line: windows this rank evaluates per step and what the collective costs per step
+    per = (nwin + world - 1) // world
+    mine = max(0, min(per, nwin - rank * per))
+    tm = net.denoise_fn.patch_timers or []
+    gather_ms = (sum(a.elapsed_time(b) for a, b in tm[-T * args.steps:]) / max(1, min(len(tm), T * args.steps))) if tm else 0.0
+    info = torch.tensor([float(mine), gather_ms], dtype=torch.float64, device=dev)
+    infos = [info.clone() for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(infos, info)
     if rank == 0:
         ws = L.ucdir_workspace_bytes(net.denoise_fn._handle())
         rec = {"metric": f"restored full-resolution images/sec at {T}-step p_sample_loop, inter-step patch split",
@@ -325,6 +335,8 @@ def patch_mode(args, net, dev, dist, rank, world, T):
                                       f"{world} rank(s), one all-gather per step",
                           "global_batch": 1, "timesteps": T, "parallelism": f"patch-shard x{world}",
                           "windows_per_step": nwin, "windows_per_engine_batch": int(net.denoise_fn.patch_max_batch),
+                          "windows_per_rank": [int(v[0].item()) for v in infos],
+                          "all_gather_ms_per_step_per_rank": [round(float(v[1].item()), 4) for v in infos],
                           "workspace_bytes_rank0": int(ws)},
                "roofline": roofline_record(rows)}
         print(json.dumps(rec))

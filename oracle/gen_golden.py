@@ -50,11 +50,46 @@ SCHED100 = dict(schedule="linear", n_timestep=100, linear_start=1e-6, linear_end
 SCHED8 = dict(schedule="linear", n_timestep=8, linear_start=1e-6, linear_end=0.4)
 
 
+def extra_full_config(net):
+    """SURVEY.md 8c fixtures (ii, B = 2) and (v, a real image) on the full SID configuration (round 3)."""
+    from ucdir_amd.weights import synth_inputs
+    # (ii) B = 2: two samples with different levels in ONE call (per-sample GroupNorm statistics, per-sample time embedding)
+    cond, guide, x_t = synth_inputs(2, 256, 256, seed=22)
+    x6 = torch.from_numpy(np.concatenate([cond, x_t], 1))
+    lv = torch.tensor([[0.05], [0.7]], dtype=torch.float32)
+    e = net.denoise_fn(x6, lv, guide=torch.from_numpy(guide))
+    rec = {"levels": lv.numpy()}
+    for b in range(2):
+        rec[f"b{b}_stats"] = np.array([e[b].mean(), e[b].std(), e[b].min(), e[b].max()], dtype=np.float64)
+        rec[f"b{b}_crop"] = e[b, :, 100:132, 60:92].numpy()
+        rec[f"b{b}_ds"] = e[b, :, ::8, ::8].numpy()
+    np.savez_compressed(os.path.join(OUT, "sid_forward_b2.npz"), **rec)
+    # (v) a real image: 256^2 crop of dataset/celebahq_64_512/sr_64_512/00030.png as the condition, the reference's own
+    # predictor output as the guide (ResiGaussianGuideDY.super_resolution, model/diffusion.py:473-478), one denoiser call
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(REF, "dataset", "celebahq_64_512", "sr_64_512", "00030.png")).convert("RGB"))
+    crop = np.ascontiguousarray(img[128:384, 128:384])                                  # (256, 256, 3) uint8
+    c = torch.from_numpy(crop).permute(2, 0, 1)[None].float() / 255.0 * 2.0 - 1.0       # [-1, 1] like data/LRHR_dataset.py
+    gpred = net.predictor(c)
+    xt = torch.from_numpy(synth_inputs(1, 256, 256, seed=23)[2])
+    lv1 = torch.tensor([[0.239415851]], dtype=torch.float32)
+    e = net.denoise_fn(torch.cat([c, xt], 1), lv1, guide=gpred)
+    np.savez_compressed(os.path.join(OUT, "sid_real_image.npz"), cond_u8=crop, level=lv1.numpy(),
+                        pred_stats=np.array([gpred.mean(), gpred.std(), gpred.min(), gpred.max()], dtype=np.float64),
+                        pred_crop=gpred[0, :, 100:132, 60:92].numpy(),
+                        eps_stats=np.array([e.mean(), e.std(), e.min(), e.max()], dtype=np.float64),
+                        eps_crop=e[0, :, 100:132, 60:92].numpy(), eps_ds=e[0, :, ::8, ::8].numpy())
+
+
 def main():
     from ucdir_amd.weights import synth_inputs
     os.makedirs(OUT, exist_ok=True)
     networks = import_reference()
     torch.set_grad_enabled(False)
+    if "--extra-only" in sys.argv:           # only the round-3 fixtures (the others are unchanged)
+        net, cfg, sd = ref_model(networks, {})
+        extra_full_config(net)
+        return
 
     # (iv) schedule tables ----------------------------------------------------------------------
     net, cfg, sd = ref_model(networks, TINY)
@@ -142,6 +177,7 @@ def main():
     rec["pred_crop"] = pred[0, :, 100:132, 60:92].numpy()
     rec["pred_stats"] = np.array([pred.mean(), pred.std(), pred.min(), pred.max()], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "sid_forward.npz"), **rec)
+    extra_full_config(net)
     print("golden written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -98,6 +98,7 @@ def main(argv=None):
                 continue
         fname = os.path.splitext(os.path.basename(val_set.sr_path[i]))[0]
         data = {k: (v.unsqueeze(0) if torch.is_tensor(v) else v) for k, v in item.items()}
+        data["Index"] = i                                         # DDPM.test offsets the rank-identical noise seed by the image index
         with torch.no_grad():
             diffusion.feed_data(data)
             diffusion.test(continous=True)

@@ -132,14 +132,49 @@ def test_forward_small_vs_oracle_and_golden(golden_dir):
     assert gm["rel_rms"] < FWD_TOL, gm
 
 
-def test_forward_sid_full_config(golden_dir, sid_net):
-    out, eps, ref = C.forward_case(SID, 1, 256, 256, [0.239415851], seed=21, taps=False, net_sd=sid_net)
+@pytest.mark.parametrize("i", [0, 1, 2], ids=["t49", "t25", "t0"])
+def test_forward_sid_full_config(golden_dir, sid_net, i):
+    """All three stored levels (t = 49: level 0.0029, where the sampler amplifies eps errors 349x; t = 25; t = 0) against the
+    oracle AND the crop / 8x-subsampled grid / statistics of the real reference's output."""
+    g = np.load(os.path.join(golden_dir, "sid_forward.npz"))
+    out, eps, ref = C.forward_case(SID, 1, 256, 256, [float(g["levels"][i])], seed=21, taps=False, net_sd=sid_net)
     assert out["eps"]["rel_rms"] < FWD_TOL, out["eps"]
-    g = np.load(os.path.join(golden_dir, "sid_forward.npz"))         # crops of the real reference's output
-    crop = eps[0, :, 100:132, 60:92]
-    gm = C.metrics(crop, torch.from_numpy(g["eps1_crop"]))
-    print("full SID forward vs oracle:", out["eps"], " crop vs reference golden:", gm)
-    assert gm["rel_rms"] < CROP_TOL, gm
+    gm = C.metrics(eps[0, :, 100:132, 60:92], torch.from_numpy(g[f"eps{i}_crop"]))
+    gd = C.metrics(eps[0, :, ::8, ::8], torch.from_numpy(g[f"eps{i}_ds"]))
+    print("full SID forward level", i, "vs oracle:", out["eps"], " crop vs reference golden:", gm, " subsampled:", gd)
+    assert gm["rel_rms"] < CROP_TOL and gd["rel_rms"] < CROP_TOL, (gm, gd)
+    st = np.array([eps.mean(), eps.std(), eps.min(), eps.max()], dtype=np.float64)
+    assert abs(st[0] - g[f"eps{i}_stats"][0]) < 0.02 * g[f"eps{i}_stats"][1] and abs(st[1] / g[f"eps{i}_stats"][1] - 1) < 0.01, (st, g[f"eps{i}_stats"])
+
+
+def test_forward_sid_full_config_b2(golden_dir, sid_net):
+    """SURVEY 8c fixture (ii), B = 2: both samples of one launch against the reference's own output."""
+    g = np.load(os.path.join(golden_dir, "sid_forward_b2.npz"))
+    out, eps, ref = C.forward_case(SID, 2, 256, 256, [float(v) for v in g["levels"].reshape(-1)], seed=22, taps=False, net_sd=sid_net)
+    assert out["eps"]["rel_rms"] < FWD_TOL, out["eps"]
+    for b in range(2):
+        gm = C.metrics(eps[b, :, 100:132, 60:92], torch.from_numpy(g[f"b{b}_crop"]))
+        gd = C.metrics(eps[b, :, ::8, ::8], torch.from_numpy(g[f"b{b}_ds"]))
+        assert gm["rel_rms"] < CROP_TOL and gd["rel_rms"] < CROP_TOL, (b, gm, gd)
+
+
+def test_real_image_through_predictor_and_denoiser(golden_dir, sid_net):
+    """SURVEY 8c fixture (v): a 256^2 crop of the reference's own sample image as the condition; the HIP predictor's output
+    is the guide of the HIP denoiser (ResiGaussianGuideDY.super_resolution's wiring); both against the reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "sid_real_image.npz"))
+    net, sd = sid_net
+    from ucdir_amd.weights import synth_inputs
+    dev = torch.device("cuda")
+    c = (torch.from_numpy(g["cond_u8"]).permute(2, 0, 1)[None].float() / 255.0 * 2.0 - 1.0).to(dev)
+    xt = torch.from_numpy(synth_inputs(1, 256, 256, seed=23)[2]).to(dev)
+    with torch.no_grad():
+        pred = net.predictor(c)
+        eps = net.denoise_fn(torch.cat([c, xt], 1), torch.from_numpy(g["level"]).to(dev), pred).cpu()
+    pm = C.metrics(pred.cpu()[0, :, 100:132, 60:92], torch.from_numpy(g["pred_crop"]))
+    gm = C.metrics(eps[0, :, 100:132, 60:92], torch.from_numpy(g["eps_crop"]))
+    gd = C.metrics(eps[0, :, ::8, ::8], torch.from_numpy(g["eps_ds"]))
+    print("real image: predictor", pm, " eps crop", gm, " eps subsampled", gd)
+    assert pm["rel_rms"] < 1.5e-2 and gm["rel_rms"] < CROP_TOL + 5e-3 and gd["rel_rms"] < CROP_TOL + 5e-3, (pm, gm, gd)   # the guide itself carries the predictor's bf16 error
 
 
 def test_time_embedding_direct(sid_net):

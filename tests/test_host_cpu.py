@@ -177,7 +177,8 @@ def _dy3h_worker(rank, world, port, q):
     holder.netG = type("G", (), {})()
     holder.netG.denoise_fn = net
     holder.setup_distributed()
-    assert net.patch_group is dist.group.WORLD and holder.netG.noise_seed is not None
+    # (the seed itself is installed per image by DDPM.test, only for images the ranks restore together)
+    assert net.patch_group is dist.group.WORLD and holder._shared_noise_seed is not None
     torch.manual_seed(0)
     x = torch.randn(1, 6, 150, 210); g = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
     q.put((rank, net(x, t, g).numpy()))
@@ -324,3 +325,85 @@ def test_launch_plan_split_factors():
         assert ks >= 1 and wgs * ks <= 512 and nch // ks >= 2 or ks == 1
     assert [plan(b"usplit", n, 0, 0, 0.0) for n in (768, 256, 48, 16, 3072)] == [2, 2, 4, 4, 1]
     assert plan(b"nonsense", 1, 1, 1, 0.0) == -1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 3: per-module patch cache, per-image rank-identical noise, in-place weight updates are noticed
+# ------------------------------------------------------------------------------------------------------------------
+def test_patch_cache_is_per_module_and_cleared():
+    """Two DY3h modules alternate on different guides without evicting each other's padded windows; the work buffers
+    (denoised canvas) persist across steps and clear_patch_cache() releases everything."""
+    a, b = _dy3h_stub(), _dy3h_stub()
+    torch.manual_seed(2)
+    x = torch.randn(1, 6, 150, 210); ga = torch.randn(1, 3, 150, 210); gb = torch.randn(1, 3, 150, 210); t = torch.tensor([[0.3]])
+    ra = O.patch_forward_guide(x, _toy_net, t, ga, skip=96, padding=16)
+    rb = O.patch_forward_guide(x, _toy_net, t, gb, skip=96, padding=16)
+    for _ in range(2):
+        assert torch.allclose(a(x, t, ga), ra, atol=1e-6) and torch.allclose(b(x, t, gb), rb, atol=1e-6)
+    ka, kb = a._patch_cache["guide"], b._patch_cache["guide"]
+    assert ka[2] is ga and kb[2] is gb and a._patch_cache is not b._patch_cache
+    den = a._patch_cache["den"][1]
+    a(x, t, ga)
+    assert a._patch_cache["den"][1] is den and a._patch_cache["guide"] is ka        # reused, not re-cut / re-allocated
+    a.clear_patch_cache()
+    assert a._patch_cache == {} and "guide" in b._patch_cache
+    from ucdir_amd import patch as P
+    assert not hasattr(P, "_GUIDE_WINDOWS")
+
+
+def test_noise_seed_is_per_image_and_only_for_sharded_images():
+    """DDPM.test installs the rank-identical generator only for images the ranks restore together, offset by the image
+    index: small (strided) images keep independent default noise, two sharded images do not share their noise."""
+    from ucdir_amd import model as M
+    from ucdir_amd.diffusion import GaussianDiffusion
+    calls = []
+
+    class G:
+        noise_seed = None
+        noise_index = 0
+
+        def __init__(self):
+            self.denoise_fn = type("D", (), {"patch_group": object(), "patch_threshold": 200 * 200})()
+
+        def eval(self):
+            pass
+
+        def super_resolution(self, sr, continous):
+            calls.append((self.noise_seed, self.noise_index, tuple(sr.shape[-2:])))
+            return sr
+
+    h = M.DDPM.__new__(M.DDPM)
+    h.netG = G(); h._shared_noise_seed = 77
+    for idx, size in ((3, 100), (4, 66), (5, 100)):
+        h.data = {"SR": torch.zeros(1, 3, size, size), "Index": torch.tensor([idx])}
+        h.test()
+    assert calls == [(77, 3, (228, 228)), (None, 4, (194, 194)), (77, 5, (228, 228))]
+    # the generator seed really differs per image and is reproducible
+    gd = GaussianDiffusion.__new__(GaussianDiffusion)
+    gd.noise_seed, gd.noise_source = 77, None
+    seeds = []
+    for idx in (3, 5, 3):
+        gd.noise_index = idx
+        gd._start_noise(torch.device("cpu"))
+        seeds.append(gd._gen.initial_seed())
+    assert seeds[0] == seeds[2] != seeds[1]
+
+
+def test_in_place_weight_updates_change_the_signature():
+    """optimizer.step / p.data.copy_ / nn.init do not pass through load_state_dict or _apply: the signature DY3h and
+    UNetSeeInDark compare once per image (prepare_guide / forward) must change."""
+    from ucdir_amd.ucdir import DY3h, UNetSeeInDark
+    for net in (DY3h(inner_channel=64, channel_mults=(1, 2), res_blocks=1, attn_res=(64,)), UNetSeeInDark()):
+        s0 = net._weights_signature()
+        assert s0 == net._weights_signature()
+        p = list(net.parameters())[7]
+        with torch.no_grad():
+            p.mul_(1.0001)
+        s1 = net._weights_signature()
+        assert s1 != s0
+        with torch.no_grad():
+            list(net.parameters())[3].data.copy_(torch.zeros_like(list(net.parameters())[3]))
+        s2 = net._weights_signature()
+        assert s2 != s1
+        torch.nn.init.normal_(list(net.parameters())[0])
+        assert net._weights_signature() != s2

@@ -110,13 +110,14 @@ def test_small_forward(golden_dir):
     np.testing.assert_allclose(eps.numpy(), ref, rtol=2e-3, atol=2e-3)
 
 
-def test_sid_forward_full_config(golden_dir):
+@pytest.mark.parametrize("i", [0, 1, 2], ids=["t49", "t25", "t0"])
+def test_sid_forward_full_config(golden_dir, i):
+    """All three stored noise levels: t = 49 (level 0.0029, where sqrt_recipm1 = 349 amplifies eps errors most), t = 25, t = 0."""
     g = _g(golden_dir, "sid_forward.npz")
     from ucdir_amd.weights import synth_inputs
     sd = O.to_torch_sd(synth_state_dict(SID, 0))
     cond, guide, x_t = synth_inputs(1, 256, 256, seed=21)
     x6 = torch.cat([_t(cond), _t(x_t)], 1)
-    i = 1
     e = O.dy3h_forward(sd, x6, torch.tensor([[g["levels"][i]]], dtype=torch.float32), _t(guide))
     np.testing.assert_allclose(e[0, :, 100:132, 60:92].numpy(), g[f"eps{i}_crop"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(e[0, :, ::8, ::8].numpy(), g[f"eps{i}_ds"], rtol=0, atol=1e-4)
@@ -124,3 +125,34 @@ def test_sid_forward_full_config(golden_dir):
     np.testing.assert_allclose(st, g[f"eps{i}_stats"], rtol=1e-4, atol=1e-5)
     pred = O.predictor_forward(sd, _t(cond))
     np.testing.assert_allclose(pred[0, :, 100:132, 60:92].numpy(), g["pred_crop"], rtol=0, atol=1e-4)
+
+
+def test_sid_forward_full_config_b2(golden_dir):
+    """SURVEY 8c fixture (ii), B = 2: two samples with different levels in one call of the reference."""
+    g = _g(golden_dir, "sid_forward_b2.npz")
+    from ucdir_amd.weights import synth_inputs
+    sd = O.to_torch_sd(synth_state_dict(SID, 0))
+    cond, guide, x_t = synth_inputs(2, 256, 256, seed=22)
+    e = O.dy3h_forward(sd, torch.cat([_t(cond), _t(x_t)], 1), _t(g["levels"]), _t(guide))
+    for b in range(2):
+        np.testing.assert_allclose(e[b, :, 100:132, 60:92].numpy(), g[f"b{b}_crop"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(e[b, :, ::8, ::8].numpy(), g[f"b{b}_ds"], rtol=0, atol=1e-4)
+        st = np.array([e[b].mean(), e[b].std(), e[b].min(), e[b].max()], dtype=np.float64)
+        np.testing.assert_allclose(st, g[f"b{b}_stats"], rtol=1e-4, atol=1e-5)
+
+
+def test_sid_real_image(golden_dir):
+    """SURVEY 8c fixture (v): a 256^2 crop of the reference's dataset/celebahq_64_512/sr_64_512/00030.png as the condition,
+    predictor output as the guide (super_resolution's wiring), one denoiser call."""
+    g = _g(golden_dir, "sid_real_image.npz")
+    from ucdir_amd.weights import synth_inputs
+    sd = O.to_torch_sd(synth_state_dict(SID, 0))
+    c = torch.from_numpy(g["cond_u8"]).permute(2, 0, 1)[None].float() / 255.0 * 2.0 - 1.0
+    pred = O.predictor_forward(sd, c)
+    np.testing.assert_allclose(pred[0, :, 100:132, 60:92].numpy(), g["pred_crop"], rtol=0, atol=1e-4)
+    xt = _t(synth_inputs(1, 256, 256, seed=23)[2])
+    e = O.dy3h_forward(sd, torch.cat([c, xt], 1), _t(g["level"]), pred)
+    np.testing.assert_allclose(e[0, :, 100:132, 60:92].numpy(), g["eps_crop"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(e[0, :, ::8, ::8].numpy(), g["eps_ds"], rtol=0, atol=1e-4)
+    st = np.array([e.mean(), e.std(), e.min(), e.max()], dtype=np.float64)
+    np.testing.assert_allclose(st, g["eps_stats"], rtol=1e-4, atol=1e-5)

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <array>
 #include <memory>
@@ -163,8 +164,10 @@ template <int TM> static void set_cgemm_attrs() {
     set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024);
 }
 #define SPLITK_MAX_WGS 512
-static std::map<int, float*> g_splitk_buf;     // split-K scratch per device (see splitk_scratch)
+static std::map<int, float*> g_splitk_buf;     // split-K scratch per device for the single-operator entry points (contexts own theirs)
+static std::mutex g_static_mu;                 // the process-global memos below (attribute set, scratch map, tile / CU-count memos)
 static void ensure_kernel_attrs() {
+    std::lock_guard<std::mutex> lk(g_static_mu);
     static std::set<int> done;
     int dev = 0;
     HIPC(hipGetDevice(&dev));
@@ -266,6 +269,8 @@ static Act make_act(DevPool& pool, int B, int H, int W, int C, bool with_stats =
 // pick the th x tw pixel tile (th*tw <= 256, halo <= 324 px) with the best MFMA-slot utilisation
 static void choose_tile(int H, int W, int& th, int& tw) {
     static std::map<std::pair<int, int>, std::pair<int, int>> memo;       // ~16k candidates: once per (H, W), not per launch
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     auto it = memo.find({H, W});
     if (it != memo.end()) { th = it->second.first; tw = it->second.second; return; }
     double best = -1; th = 16; tw = 16;
@@ -318,6 +323,8 @@ static int g_persist_grid = 0;      // > 0: ucdir_debug_flag("persist_grid", n) 
 static int num_cus() {
     if (g_persist_grid > 0) return g_persist_grid;
     static std::map<int, int> memo;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     int dev = 0;
     HIPC(hipGetDevice(&dev));
     auto it = memo.find(dev);
@@ -330,7 +337,10 @@ static int num_cus() {
 }
 
 // split-K scratch: raw fp32 partial tiles of at most SPLITK_MAX_WGS workgroups of 256 px x 128 rows (64 MiB), one per device, allocated with the kernel attributes (never on the launch path: forwards are captured into HIP graphs)
+static thread_local float* t_splitk = nullptr;      // set by forward() to the running context's own scratch
 static float* splitk_scratch() {
+    if (t_splitk) return t_splitk;
+    std::lock_guard<std::mutex> lk(g_static_mu);
     int dev = 0;
     HIPC(hipGetDevice(&dev));
     auto it = g_splitk_buf.find(dev);
@@ -889,11 +899,14 @@ struct ucdir_ctx {
     struct FwdGraph { const void *cond, *xt, *lvl, *eps; hipGraph_t g; hipGraphExec_t ex; };
     std::vector<FwdGraph> graphs;
     hipStream_t cap_stream = nullptr;
+    int miss_streak = 0;                                   // consecutive forwards whose pointer set was not cached
+    const void* last_miss[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* splitk = nullptr;                               // this context's split-K scratch (two handles on two streams of one device do not share partial sums)
     void drop_graphs() {
         for (auto& f : graphs) { (void)hipGraphExecDestroy(f.ex); (void)hipGraphDestroy(f.g); }
-        graphs.clear();
+        graphs.clear(); miss_streak = 0; last_miss[0] = nullptr;
     }
-    ~ucdir_ctx() { drop_graphs(); if (cap_stream) (void)hipStreamDestroy(cap_stream); }
+    ~ucdir_ctx() { drop_graphs(); if (cap_stream) (void)hipStreamDestroy(cap_stream); if (splitk) (void)hipFree(splitk); }
 };
 
 static std::vector<std::string> expected_names(const ucdir_config& c, const std::vector<LayerDesc>& L) {
@@ -1040,6 +1053,7 @@ struct ActPlanner {
 
 static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     c->apool.release();
+    if (!c->splitk) HIPC(hipMalloc((void**)&c->splitk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));   // (planning never runs under a stream capture)
     c->rt.assign(c->layers.size(), LayerRT());
     c->B = B; c->H = H; c->W = W; c->pad_mode = pad_mode;
     if (pad_mode) { c->Hc = (H / 32 + 1) * 32; c->Wc = (W / 32 + 1) * 32; require(H >= 33 && W >= 33, "H, W must be >= 33 (reflect pad)"); }
@@ -1109,6 +1123,7 @@ static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
 }
 
 static void forward(ucdir_ctx* c, const float* cond, const float* xt, const float* level, float* eps, hipStream_t st) {
+    struct ScratchScope { ScratchScope(float* p) { t_splitk = p; } ~ScratchScope() { t_splitk = nullptr; } } scratch_scope(c->splitk);
     c->apool.zero_stats(st);          // every activation's (sum, sum of squares) accumulator, see stat_add()
     require(c->finalized, "weights not finalized");
     require(c->guide_ready, "ucdir_prepare_guide must be called before ucdir_unet_forward");
@@ -1177,8 +1192,16 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
 // legacy default stream cannot be captured); nothing on the launch path allocates or synchronises.
 static void forward_graph(ucdir_ctx* c, const float* cond, const float* xt, const float* level, float* eps, hipStream_t st) {
     for (auto& f : c->graphs)
-        if (f.cond == cond && f.xt == xt && f.lvl == level && f.eps == eps) { HIPC(hipGraphLaunch(f.ex, st)); return; }
-    if (c->graphs.size() >= 8) c->drop_graphs();                 // callers that keep changing pointers: bounded cache
+        if (f.cond == cond && f.xt == xt && f.lvl == level && f.eps == eps) { c->miss_streak = 0; HIPC(hipGraphLaunch(f.ex, st)); return; }
+    // Miss.  Callers with persistent buffers (p_sample_loop) miss once per buffer set; callers that hand over fresh tensors
+    // every step (p_sample, the ddim / dpm-solver samplers) would re-capture and re-instantiate a ~150-node graph - plus a
+    // stream synchronisation - on every forward: after two misses in a row a pointer set is launched eagerly unless it is
+    // the very set that missed last time (then it IS persistent and worth a capture).
+    const bool same_as_last = c->last_miss[0] == cond && c->last_miss[1] == xt && c->last_miss[2] == level && c->last_miss[3] == eps;
+    c->last_miss[0] = cond; c->last_miss[1] = xt; c->last_miss[2] = level; c->last_miss[3] = eps;
+    if (c->miss_streak >= 2 && !same_as_last) { ++c->miss_streak; forward(c, cond, xt, level, eps, st); return; }
+    ++c->miss_streak;
+    if (c->graphs.size() >= 8) { const int ms = c->miss_streak; c->drop_graphs(); c->miss_streak = ms; }   // bounded cache
     if (!c->cap_stream) HIPC(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIPC(hipStreamSynchronize(st));                              // inputs produced on the caller's stream are complete
     ucdir_ctx::FwdGraph f{cond, xt, level, eps, nullptr, nullptr};
@@ -1186,7 +1209,10 @@ static void forward_graph(ucdir_ctx* c, const float* cond, const float* xt, cons
     try { forward(c, cond, xt, level, eps, c->cap_stream); }
     catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(c->cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
     HIPC(hipStreamEndCapture(c->cap_stream, &f.g));
-    HIPC(hipGraphInstantiate(&f.ex, f.g, nullptr, nullptr, 0));
+    if (hipGraphInstantiate(&f.ex, f.g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(f.g);
+        throw std::runtime_error("hipGraphInstantiate failed for a captured forward");
+    }
     c->graphs.push_back(f);
     HIPC(hipGraphLaunch(f.ex, st));
 }

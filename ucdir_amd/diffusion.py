@@ -62,6 +62,7 @@ class GaussianDiffusion(nn.Module):
         self.conditional = conditional
         self.noise_source = None     # optional callable(shape, device, k) -> tensor, for injected noise
         self.noise_seed = None       # optional int: rank-identical device generator (sharded patch split)
+        self.noise_index = 0         # per-image offset of the seed (sr.py sets the dataset index before every restoration)
         self._gen = None
 
     def set_loss(self, device):
@@ -118,8 +119,10 @@ class GaussianDiffusion(nn.Module):
         """(Re)seed the rank-identical generator at the start of a sampling loop."""
         self._gen = None
         if self.noise_seed is not None and self.noise_source is None:
+            # noise_index (set by the caller per image, e.g. the dataset index) keeps the noise of different images
+            # independent while every rank of a sharded restoration still draws the identical sequence
             self._gen = torch.Generator(device=device)
-            self._gen.manual_seed(int(self.noise_seed))
+            self._gen.manual_seed(int(self.noise_seed) + 1000003 * int(self.noise_index))
 
     def _eps(self, cond, x, lvl, guide, out=None):
         if self._small(x):
@@ -184,6 +187,9 @@ class GaussianDiffusion(nn.Module):
             if i % sample_inter == 0:
                 ret.append(img.clone())
         self._gen = None
+        clr = getattr(self.denoise_fn, "clear_patch_cache", None)
+        if clr is not None:
+            clr()                                             # padded guide windows / gather buffers of this restoration
         if continous:
             return torch.cat(ret, dim=0)
         return ret[-1]

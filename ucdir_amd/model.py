@@ -40,7 +40,8 @@ class DDPM:
             return
         g = group if group is not None else dist.group.WORLD
         self.netG.denoise_fn.patch_group = g
-        self.netG.noise_seed = noise_seed          # every rank must apply the identical sampler update
+        self._shared_noise_seed = noise_seed       # every rank must apply the identical sampler update to a SHARDED image;
+        self.netG.noise_seed = None                # test() installs the seed only for images that take the sharded patch split
 
     def feed_data(self, data):
         self.data = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
@@ -49,6 +50,15 @@ class DDPM:
         self.netG.eval()
         pd = 64
         sr = F.pad(self.data["SR"], (pd, pd, pd, pd), mode="reflect")
+        dn = self.netG.denoise_fn
+        seed = getattr(self, "_shared_noise_seed", None)
+        sharded = seed is not None and dn.patch_group is not None and sr.shape[-1] * sr.shape[-2] > dn.patch_threshold
+        if seed is not None:
+            # rank-identical noise only where the ranks cooperate on one image; its seed is offset by the image index
+            # (data["Index"] when the loader provides it) so that images stay independent of each other and of the world size
+            self.netG.noise_seed = seed if sharded else None
+            idx = self.data.get("Index", 0)
+            self.netG.noise_index = int(idx.reshape(-1)[0]) if torch.is_tensor(idx) else int(idx or 0)
         with torch.no_grad():
             out = self.netG.super_resolution(sr, continous)
         self.SR = out[..., pd:-pd, pd:-pd]

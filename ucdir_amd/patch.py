@@ -28,23 +28,36 @@ def patch_pad(H, W, skip, padding):
     return skip - pd + padding if pd < skip else padding
 
 
-_GUIDE_WINDOWS = {}      # the guide does not change over the steps of a restoration: its padded windows are cut once
-
-
-def _guide_chunks(guide, pd, chunks):
+def _guide_chunks(guide, pd, chunks, cache):
+    """Padded guide windows, cut once per restoration (the guide does not change over the steps).  ``cache`` is a dict
+    owned by the CALLER (DY3h keeps one per module and clears it at the end of a sampling loop): nothing global keeps
+    hundreds of MB of windows alive, and two modules never evict each other."""
     key = (guide.data_ptr(), guide._version, tuple(guide.shape), pd, tuple(map(tuple, chunks)))
-    hit = _GUIDE_WINDOWS.get("k")
+    hit = cache.get("guide")
     if hit is not None and hit[0] == key:
         return hit[1]
     gp = F.pad(guide, (pd, pd, pd, pd), mode="reflect")
     out = [torch.cat([gp[..., a:b, c:d] for (a, b, c, d) in ch], dim=0).contiguous() for ch in chunks]
-    _GUIDE_WINDOWS["k"] = (key, out, guide)          # one entry; keeps `guide` alive so the key cannot be recycled
+    cache["guide"] = (key, out, guide)               # one entry; keeps `guide` alive so the key cannot be recycled
     return out
 
 
-def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, max_batch=8):
+def _buffer(cache, name, shape, like):
+    """Persistent work buffer of a restoration (gather slots, denoised canvas): allocated once, reused every step."""
+    key = (tuple(shape), like.dtype, like.device)
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.zeros(shape, dtype=like.dtype, device=like.device))
+        cache[name] = hit
+    return hit[1]
+
+
+def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, max_batch=8, cache=None, force_gather=False,
+                        timers=None):
     """Same result as the reference's sequential loop; ``net(x, time=..., guide=...)`` is called on
     batches of windows.  noisy (B,6,H,W); params = {'time': (B,1), 'guide': (B,3,H,W)}."""
+    if cache is None:
+        cache = {}
     B = noisy.shape[0]
     pd = patch_pad(noisy.shape[-2], noisy.shape[-1], skip, padding)
     xp = F.pad(noisy, (pd, pd, pd, pd), mode="reflect")
@@ -67,7 +80,7 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
             chunk = mine[s:s + size]
             reals.append(len(chunk))
             chunks.append(chunk + [chunk[-1]] * (size - len(chunk)))
-        gbs = _guide_chunks(params["guide"], pd, chunks)
+        gbs = _guide_chunks(params["guide"], pd, chunks, cache)
         for chunk, real, gb in zip(chunks, reals, gbs):
             xb = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
             tb = params["time"].repeat(len(chunk), 1)
@@ -78,16 +91,22 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
         local = torch.cat(outs, dim=0)
     else:
         local = xp.new_zeros((0, 3, inner, inner))
-    if world > 1:
+    if world > 1 or (force_gather and group is not None):
+        # ONE collective per step into buffers that live for the whole restoration (fixed-size slots: `per` windows per rank)
         import torch.distributed as dist
-        slot = xp.new_zeros((per * B, 3, inner, inner))
+        slot = _buffer(cache, "slot", (per * B, 3, inner, inner), xp)
+        allo = _buffer(cache, "gathered", (world * per * B, 3, inner, inner), xp)
         slot[:local.shape[0]] = local
-        gathered = [torch.empty_like(slot) for _ in range(world)]
-        dist.all_gather(gathered, slot, group=group)
-        allo = torch.cat(gathered, dim=0)
+        if timers is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        dist.all_gather_into_tensor(allo, slot, group=group)
+        if timers is not None:
+            ev[1].record()
+            timers.append(ev)
     else:
         allo = local
-    den = torch.zeros_like(xp)[:, :3]
+    den = _buffer(cache, "den", (B, 3, H, W), xp)      # every interior pixel is overwritten below; the border is cropped
     for k, (a, b, c, d) in enumerate(wins):        # reference order: later windows overwrite earlier ones
         r, q = divmod(k, per)
         base = (r * per + q) * B

@@ -59,6 +59,17 @@ def _default_init(name, shape):
     return t
 
 
+def _param_signature(ps):
+    """Cheap fingerprint of a parameter list: storage identity, autograd version counters (in-place ops, optimizer.step,
+    nn.init) and a CONTENT checksum (sum of the L1 and L2 norms: ``p.data.copy_(ema)`` writes through the ``.data`` alias and
+    bumps no version counter).  One multi-tensor launch and one host read - evaluated once per image, not per step."""
+    with torch.no_grad():
+        n1 = torch.stack(torch._foreach_norm(ps, 1)).double().sum()
+        n2 = torch.stack(torch._foreach_norm(ps, 2)).double().sum()
+        chk = (float(n1), float(n2))
+    return (len(ps), sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), chk)
+
+
 class DY3h(nn.Module):
     """Conditional UNet denoiser; same signature as the reference's ``DY3h`` (model/ucdir.py:204-207)."""
 
@@ -89,17 +100,31 @@ class DY3h(nn.Module):
         self.patch_skip, self.patch_padding = 1024, 64
         self.patch_group = None              # torch.distributed group: windows of a step are sharded over its ranks
         self.patch_max_batch = 8             # windows per engine call (1024^2 windows: 2.3 GB of workspace each)
+        self.patch_force_gather = False      # tests: run the all-gather branch even on a one-rank group (RCCL init + collective on hardware)
+        self.patch_timers = None             # optional list: (start, end) CUDA events of every all-gather (bench.py --mode patch)
+        self._patch_cache = {}               # padded guide windows + gather / paste buffers of the running restoration
         self.use_graph = False               # replay each forward from a HIP graph (B = 1 latency path)
         self._h = None
+        self._hdev = None                    # device index the engine handle was created on
         self._wdirty = True                  # parameters changed since the engine packed them
+        self._wsig = None                    # signature of the parameter storage the engine packed (see _weights_signature)
         self._gkey = None
+
+    def clear_patch_cache(self):
+        """Drop the padded guide windows and gather buffers of the last patch-split restoration (hundreds of MB at full size)."""
+        self._patch_cache.clear()
 
     # ---- weight-change tracking: O(1) per forward ------------------------------------------------
     # Every path that replaces or rewrites parameter storage in this repo's scope goes through one of these hooks
     # (load_state_dict, .to() / .cuda() / .float() via _apply).  Code that mutates ``p.data`` in place must call
-    # ``mark_weights_dirty()``.
+    # ``mark_weights_dirty()``.  In addition ``prepare_guide`` re-checks a cheap signature of the parameters (_param_signature:
+    # version counters + content checksum) whenever the guide changes, i.e. once per image: in-place updates that bypass the
+    # hooks (optimizer.step, ``p.data.copy_(ema)``, ``vector_to_parameters``, ``nn.init.*``) are picked up before the next restoration.
     def mark_weights_dirty(self):
         self._wdirty = True
+
+    def _weights_signature(self):
+        return _param_signature(list(self.parameters()))
 
     def _apply(self, fn, *a, **k):
         self._wdirty = True
@@ -122,6 +147,10 @@ class DY3h(nn.Module):
 
     def _handle(self):
         L = _lib.load()
+        if self._h is not None and self._hdev != self._device_index():
+            # the module moved to another GPU (.to('cuda:1')): the handle, its packed weights and workspace live on the old one
+            L.ucdir_destroy(self._h)
+            self._h, self._wdirty, self._gkey = None, True, None
         if self._h is None:
             c = _lib.UcdirConfig()
             cfg = self.cfg
@@ -137,11 +166,12 @@ class DY3h(nn.Module):
             h = ctypes.c_void_p()
             _lib.check(L.ucdir_create(ctypes.byref(c), ctypes.byref(h)))
             self._h = h
+            self._hdev = c.device
         return self._h
 
     def _sync_weights(self):
         """(Re)pack weights into the engine when parameters changed (load_state_dict, .to, mark_weights_dirty)."""
-        if not self._wdirty and self._h is not None:
+        if not self._wdirty and self._h is not None and self._hdev == self._device_index():
             return
         L = _lib.load()
         h = self._handle()
@@ -152,6 +182,7 @@ class DY3h(nn.Module):
         _lib.check(L.ucdir_finalize_weights(h))
         _lib.check(L.ucdir_set_graph(h, 1 if self.use_graph else 0))
         self._wdirty = False
+        self._wsig = self._weights_signature()
         self._gkey = None
 
     def set_graph(self, on=True):
@@ -170,9 +201,11 @@ class DY3h(nn.Module):
 
     def prepare_guide(self, guide, pad_mode=1):
         L = _lib.load()
+        key = (guide.data_ptr(), guide._version, tuple(guide.shape), tuple(guide.stride()), pad_mode)
+        if key != self._gkey and not self._wdirty and self._wsig != self._weights_signature():
+            self._wdirty = True                 # a parameter was updated in place since the engine packed the weights
         self._sync_weights()
         self._check_dev("guide", guide)
-        key = (guide.data_ptr(), guide._version, tuple(guide.shape), tuple(guide.stride()), pad_mode)
         if key != self._gkey:
             g = guide.contiguous().float()
             B, _, H, W = g.shape
@@ -220,7 +253,8 @@ class DY3h(nn.Module):
         if h * w > self.patch_threshold:
             return patch_forward_guide(x, self.naiveforward, params={"time": time, "guide": guide},
                                        skip=self.patch_skip, padding=self.patch_padding, group=self.patch_group,
-                                       max_batch=self.patch_max_batch)
+                                       max_batch=self.patch_max_batch, cache=self._patch_cache,
+                                       force_gather=self.patch_force_gather, timers=self.patch_timers)
         return self.forward_split(x[:, :3], x[:, 3:], time, guide, pad_mode=1)
 
     def debug_read(self, layer, what="out"):
@@ -303,20 +337,32 @@ class UNetSeeInDark(nn.Module):
         self._wdirty = True
         return super()._load_from_state_dict(*a, **k)
 
+    def _device_index(self):
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise _lib.UcdirError("UNetSeeInDark runs only on an MI355X (move the module to 'cuda'); there is no CPU path")
+        return p.device.index if p.device.index is not None else torch.cuda.current_device()
+
     def _handle(self):
         L = _lib.load()
+        dev = self._device_index()
+        if self._h is not None and getattr(self, "_hdev", None) != dev:      # moved to another GPU: rebuild there
+            L.ucdir_predictor_destroy(self._h)
+            self._h, self._wdirty = None, True
         if self._h is None:
-            p = next(self.parameters())
-            if p.device.type != "cuda":
-                raise _lib.UcdirError("UNetSeeInDark runs only on an MI355X (move the module to 'cuda'); there is no CPU path")
-            dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
             h = ctypes.c_void_p()
             _lib.check(L.ucdir_predictor_create(dev, ctypes.byref(h)))
-            self._h = h
+            self._h, self._hdev = h, dev
         return self._h
 
+    def _weights_signature(self):
+        return _param_signature(list(self.parameters()))
+
     def _sync_weights(self):
-        if not self._wdirty and self._h is not None:
+        # the predictor runs once per image: the in-place-update check (see DY3h._weights_signature) costs 46 attribute reads
+        if not self._wdirty and self._h is not None and getattr(self, "_wsig", None) != self._weights_signature():
+            self._wdirty = True
+        if not self._wdirty and self._h is not None and getattr(self, "_hdev", None) == self._device_index():
             return
         L = _lib.load()
         h = self._handle()
@@ -326,6 +372,7 @@ class UNetSeeInDark(nn.Module):
             _lib.check(L.ucdir_predictor_load_weight(h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
         _lib.check(L.ucdir_predictor_finalize(h))
         self._wdirty = False
+        self._wsig = self._weights_signature()
 
     def forward(self, x):
         L = _lib.load()
