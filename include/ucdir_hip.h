@@ -160,6 +160,14 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1,
                       const float* gamma_host, const float* beta_host,
                       int32_t cout, int32_t ksize, int32_t mode, int32_t silu,
                       const float* residual, float* y, double* stats_out_host, void* stream);
+/* conv1 of a residual block + the block's 1x1 res_conv on the same concatenated input in one launch (ABI 3; the launch the
+ * UNet's "ups" blocks issue, model/ucdir.py:110,120): y = act(conv3x3(GN(cat[x0,x1]))), yres = conv1x1(cat[x0,x1]) + bres */
+int32_t ucdir_op_conv_res(const float* x0, int32_t c0, const float* x1, int32_t c1,
+                          int32_t B, int32_t H, int32_t W,
+                          const float* w_host, const float* bias_host,
+                          const float* gamma_host, const float* beta_host,
+                          const float* wres_host, const float* bres_host,
+                          int32_t cout, int32_t silu, float* y, float* yres, double* stats_out_host, void* stream);
 /* AKGM block tail: y = swish(sum_s spdyconv(GN2(h))[c,s] * att[s]) + res
  * h: (B,C,H,W); att: (B,8,H,W) (= conv2(guide) * attw, already multiplied); res: (B,C,H,W);
  * stats_out_host (ABI 3, may be NULL): (B,2) doubles = the (sum, sum of squares) the launch accumulated for y. */

@@ -96,6 +96,41 @@ def conv_case(B, H, W, c0, c1, cout, ksize, mode, gn, silu, residual, seed=0):
     return m
 
 
+def conv_res_case(B, H, W, c0, c1, cout, seed=0):
+    """ucdir_op_conv_res (conv1 with GroupNorm fold + swish, and the block's 1x1 res_conv, one launch) vs torch."""
+    L = ulib.load()
+    g = rng(seed)
+    cin = c0 + c1
+    x0 = bfr(torch.randn(B, c0, H, W, generator=g) * 1.3 + 0.6)
+    x1 = bfr(torch.randn(B, c1, H, W, generator=g) * 0.7 - 0.4) if c1 else None
+    w = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(1.5 / (cin * 9))
+    b = torch.randn(cout, generator=g) * 0.1
+    wr = torch.randn(cout, cin, 1, 1, generator=g) * math.sqrt(1.5 / cin)
+    br = torch.randn(cout, generator=g) * 0.1
+    gamma = 1 + 0.25 * torch.randn(cin, generator=g)
+    beta = 0.2 * torch.randn(cin, generator=g)
+    x = torch.cat([x0, x1], 1) if c1 else x0
+    y = O.swish(F.conv2d(F.group_norm(x, 1, gamma, beta, eps=1e-5), w, b, padding=1))
+    yr = F.conv2d(x, wr, br)
+    dx0, dx1 = x0.to(DEV), (x1.to(DEV) if c1 else None)
+    dy = torch.empty(B, cout, H, W, device=DEV); dyr = torch.empty(B, cout, H, W, device=DEV)
+    stats = np.zeros((B, 2), dtype=np.float64)
+    ulib.check(L.ucdir_op_conv_res(_p(dx0), c0, _p(dx1), c1, B, H, W, _hp(w.numpy().copy()), _hp(b.numpy().copy()),
+                                   _hp(gamma.numpy().copy()), _hp(beta.numpy().copy()), _hp(wr.numpy().copy()), _hp(br.numpy().copy()),
+                                   cout, 1, _p(dy), _p(dyr), _hp(stats), _st()))
+    torch.cuda.synchronize()
+    m = metrics(dy, y)
+    mr = metrics(dyr, yr)
+    m["res_rel_rms"], m["res_nan"] = mr["rel_rms"], mr["nan"]
+    got = dy.double().cpu()
+    st_ref = np.stack([got.sum(dim=(1, 2, 3)).numpy(), got.pow(2).sum(dim=(1, 2, 3)).numpy()], 1)
+    m["stats_rel"] = float(np.abs(stats - st_ref).max() / np.abs(st_ref).max())
+    d = (dy.cpu() - y).abs()
+    m["max_abs_border"] = float(torch.cat([d[..., 0, :].flatten(), d[..., -1, :].flatten(), d[..., :, 0].flatten(),
+                                           d[..., :, -1].flatten()]).max())
+    return m
+
+
 def akgm_case(B, C, H, W, seed=0):
     L = ulib.load()
     g = rng(seed)

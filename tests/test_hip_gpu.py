@@ -73,6 +73,27 @@ def test_conv_persistent(args):
     assert m["stats_rel"] < 1e-3, m
 
 
+@pytest.mark.parametrize("args", [
+    (3, 32, 48, 64, 64, 64, 0),        # conv_ws128: 8 x 16 tiles, one tile per workgroup, all border tiles
+    (3, 64, 80, 64, 64, 64, 7),        # persistent ranges crossing sample boundaries (grid forced to 7 workgroups)
+    (2, 288, 288, 64, 64, 64, 0),      # the network's level-0 size (ups.17 / ups.18)
+    (2, 40, 56, 128, 64, 64, 0),       # 192 -> 64: conv3x3_halo<64, true> (10th tap)
+    (2, 24, 40, 128, 64, 128, 0),      # 192 -> 128: res_conv as tail workgroups of conv3x3_halo<128>
+], ids=["ws128_small", "ws128_ranges", "ws128_level0", "tap10_192", "tail_128"])
+def test_conv_with_fused_res_conv(args):
+    """conv1 + the block's res_conv in one launch (the UNet's ups blocks), every kernel that implements it."""
+    B, H, W, c0, c1, cout, grid = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    try:
+        m = C.conv_res_case(B, H, W, c0, c1, cout, seed=4)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+    assert not m["nan"] and not m["res_nan"] and m["rel_rms"] < OP_TOL and m["res_rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m
+    assert m["stats_rel"] < 1e-3, m
+
+
 @pytest.mark.parametrize("Cc", [64, 128, 256, 512])
 def test_akgm(Cc):
     m = C.akgm_case(2, Cc, 20, 24)

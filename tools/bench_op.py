@@ -23,6 +23,20 @@ if kind == "conv":
                                    C._p(None), C._p(y), C._hp(None), C._st()))
     torch.cuda.synchronize()
     print("done", float(y.abs().mean()))
+elif kind == "convres":     # python tools/bench_op.py convres B H W c0 c1 cout [reps]
+    B, H, W, c0, c1, cout = map(int, sys.argv[2:8]); reps = int(sys.argv[8]) if len(sys.argv) > 8 else 5
+    g = C.rng(0)
+    cin = c0 + c1
+    x0 = torch.randn(B, c0, H, W, generator=g).cuda(); x1 = torch.randn(B, c1, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(1.5 / (9 * cin))).numpy().copy()
+    wr = (torch.randn(cout, cin, 1, 1, generator=g) * math.sqrt(1.5 / cin)).numpy().copy()
+    b = np.zeros(cout, np.float32); gm = np.ones(cin, np.float32); bt = np.zeros(cin, np.float32)
+    y = torch.empty(B, cout, H, W, device="cuda"); yr = torch.empty(B, cout, H, W, device="cuda")
+    for _ in range(reps):
+        ulib.check(L.ucdir_op_conv_res(C._p(x0), c0, C._p(x1), c1, B, H, W, C._hp(w), C._hp(b), C._hp(gm), C._hp(bt), C._hp(wr), C._hp(b),
+                                       cout, 1, C._p(y), C._p(yr), C._hp(None), C._st()))
+    torch.cuda.synchronize()
+    print("done", float(y.abs().mean()), float(yr.abs().mean()))
 elif kind == "akgm":
     B, H, W, Cc = map(int, sys.argv[2:6]); reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
     g = C.rng(0)

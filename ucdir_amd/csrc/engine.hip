@@ -20,6 +20,7 @@
 #include "akgm_pre.hip.h"
 #include "akgm_ws.hip.h"
 #include "conv_ws.hip.h"
+#include "conv_ws128.hip.h"
 #include "flash_attn.hip.h"
 #include "common.h"
 #include "misc.hip.h"
@@ -97,6 +98,7 @@ struct ConvW {
     bf16_t* Aup = nullptr; int Kup = 0;     // Upsample convs: parity-decomposed 2x2 weights [4][rows_pad][4*cin]
     bf16_t* A10 = nullptr; float* bias_res = nullptr;   // conv1 + the block's res_conv as a 10th tap (64-row tiles only)
     bf16_t* Aws = nullptr;                               // 3x3 64 -> 64: A fragments of the persistent weight-stationary kernel (conv_ws.hip.h)
+    bf16_t* Aws128 = nullptr;                            // 3x3 128 -> 64 + res_conv: A fragments of conv_ws128_kernel (72 steps, then the res_conv's 8)
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -180,6 +182,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel, AkWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
+    set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -452,6 +455,45 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         did_res = true;
     }
     const bool dual = did_res;                          // conv3x3_halo_kernel<64, true>: second accumulator set
+    // 128 -> 64 with the res_conv fused, on 8 x 16 tiles: persistent kernel with one wave per SIMD (conv_ws128.hip.h)
+    static const bool use_cws128 = !getenv("UCDIR_NO_CONV_WS128");
+    if (use_cws128 && did_res && w.Aws128 && cin == 128 && x0.C % 8 == 0 && !res && !p.out_nchw && y.H % 8 == 0 && y.W % 16 == 0 && y.C == 64) {
+        p.A = w.Aws128; p.alt_A = w.Aws128 + (size_t)2 * 72 * 2 * 32 * 8;
+        p.th = 8; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 8;
+        const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
+        const int grid = ntiles < ncu ? ntiles : ncu;
+#ifdef UCDIR_TIMING
+        {
+            static unsigned long long* dbgbuf = nullptr;
+            if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
+            HIPC(hipMemset(dbgbuf, 0, 256 * 8));
+            p.dbg = dbgbuf;
+            hipLaunchKernelGGL(conv_ws128_kernel, dim3(grid), dim3(CvWs128::THREADS), CvWs128::LDS, st, p);
+            unsigned long long h[256];
+            HIPC(hipStreamSynchronize(st));
+            HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
+            const int n = (int)h[255];
+            fprintf(stderr, "CONV_WS128 TIMING n=%d:", n);
+            for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, "\n");
+            return did_res;
+        }
+#endif
+        if (g_prof.on) {
+            ProfEntry e; e.key = 24; gemm_work(p, EPI_STD, e.flops, e.bytes);
+            { const double cols = (double)p.H * p.W * p.nbatch; e.flops += 2.0 * p.cg * p.nfeat * cols; e.bytes += 2.0 * p.cg * p.nfeat + 2.0 * p.nfeat * cols; }
+            e.dH = p.H; e.dW = p.W; e.dCin = p.cg; e.dCout = p.nfeat;
+            e.e0 = g_prof.get(); e.e1 = g_prof.get();
+            HIPC(hipEventRecord(e.e0, st));
+            hipLaunchKernelGGL(conv_ws128_kernel, dim3(grid), dim3(CvWs128::THREADS), CvWs128::LDS, st, p);
+            HIPC(hipEventRecord(e.e1, st));
+            g_prof.entries.push_back(e);
+        } else {
+            hipLaunchKernelGGL(conv_ws128_kernel, dim3(grid), dim3(CvWs128::THREADS), CvWs128::LDS, st, p);
+        }
+        HIPC(hipGetLastError());
+        return did_res;
+    }
     if (halo && !did_res && !p.out_nchw && w.cout % 8 == 0) {
         const int taps = upph ? 4 : 9, tps = 256 / tm_run;
         const int ks = choose_ksplit(p.nbatch * p.tiles * p.rowtiles, cin / HC_BK, (taps + tps - 1) / tps,
@@ -981,7 +1023,9 @@ static void finalize_weights(ucdir_ctx* c) {
                     PackedConv P = pack_conv(W_(c, r + "conv1.weight", (size_t)d.cout * d.cin * 9).data(), nullptr,
                                              W_(c, r + "norm1.weight", d.cin).data(), W_(c, r + "norm1.bias", d.cin).data(),
                                              d.cout, d.cin, 3, 64);
-                    w.conv.A10 = c->wpool.upload(pack_conv_res10(P, W_(c, r + "res_conv.weight", (size_t)d.cout * d.cin).data()));
+                    const std::vector<bf16_t> a10 = pack_conv_res10(P, W_(c, r + "res_conv.weight", (size_t)d.cout * d.cin).data());
+                    w.conv.A10 = c->wpool.upload(a10);
+                    if (d.cin == 128 && d.cout == 64) w.conv.Aws128 = c->wpool.upload(pack_conv_ws128(a10));
                     w.conv.bias_res = w.resconv.bias;
                 }
             }
@@ -1464,6 +1508,47 @@ int32_t ucdir_op_conv(const float* x0, int32_t c0, const float* x1, int32_t c1, 
     if (stats_out_host)
         for (int bb = 0; bb < B; ++bb)
             for (int q = 0; q < 2; ++q) {                   // fixed-point slots -> (sum, sum of squares)
+                stat_t acc = 0;
+                for (int k = 0; k < UCDIR_STAT_SLOTS; ++k) acc += sfx[((size_t)bb * UCDIR_STAT_SLOTS + k) * 2 + q];
+                stats_out_host[bb * 2 + q] = (double)acc / UCDIR_STAT_SCALE;
+            }
+    API_END
+}
+
+// conv1 (3x3, GroupNorm fold, optional swish) of a residual block together with the block's 1x1 res_conv on the same (raw,
+// concatenated) input - the launch the UNet's "ups" blocks issue (model/ucdir.py:110,120): y = act(conv3x3(GN(cat[x0,x1]))),
+// yres = conv1x1(cat[x0,x1]) + bres.  cout = 64: fused (10th tap / conv_ws128); otherwise the res_conv rides as tail workgroups.
+int32_t ucdir_op_conv_res(const float* x0, int32_t c0, const float* x1, int32_t c1, int32_t B, int32_t H, int32_t W,
+                          const float* w_host, const float* bias_host, const float* gamma_host, const float* beta_host,
+                          const float* wres_host, const float* bres_host, int32_t cout, int32_t silu,
+                          float* y, float* yres, double* stats_out_host, void* stream) {
+    API_BEGIN
+    ensure_kernel_attrs();
+    hipStream_t st = (hipStream_t)stream;
+    DevPool pool;
+    const int cin = c0 + (x1 ? c1 : 0);
+    Act a0 = act_from_nchw(pool, x0, B, c0, H, W, st, true);
+    Act a1; if (x1) a1 = act_from_nchw(pool, x1, B, c1, H, W, st, true);
+    Act out = make_act(pool, B, H, W, cout), rout = make_act(pool, B, H, W, cout, false);
+    ConvW w = upload_conv(pool, w_host, bias_host, gamma_host, beta_host, cout, cin, 3);
+    ConvW wr = upload_conv(pool, wres_host, bres_host, nullptr, nullptr, cout, cin, 1);
+    if (w.TM == 64 && cin % 64 == 0 && w.Kpad == 9 * cin) {
+        PackedConv P = pack_conv(w_host, nullptr, gamma_host, beta_host, cout, cin, 3, 64);
+        const std::vector<bf16_t> a10 = pack_conv_res10(P, wres_host);
+        w.A10 = pool.upload(a10); w.bias_res = wr.bias;
+        if (cin == 128 && cout == 64) w.Aws128 = pool.upload(pack_conv_ws128(a10));
+    }
+    const bool did = run_conv(w, a0, x1 ? &a1 : nullptr, out, COLS_S1, silu, nullptr, true, st, nullptr, 0, 0, &rout, &wr);
+    if (!did) run_conv(wr, a0, x1 ? &a1 : nullptr, rout, COLS_S1, 0, nullptr, false, st);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, out.p, y, B, cout, H, W);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(2048), dim3(256), 0, st, rout.p, yres, B, cout, H, W);
+    HIPC(hipGetLastError());
+    std::vector<stat_t> sfx;
+    if (stats_out_host) { sfx.resize((size_t)2 * UCDIR_STAT_SLOTS * B); HIPC(hipMemcpyAsync(sfx.data(), out.stats, sizeof(stat_t) * sfx.size(), hipMemcpyDeviceToHost, st)); }
+    HIPC(hipStreamSynchronize(st));
+    if (stats_out_host)
+        for (int bb = 0; bb < B; ++bb)
+            for (int q = 0; q < 2; ++q) {
                 stat_t acc = 0;
                 for (int k = 0; k < UCDIR_STAT_SLOTS; ++k) acc += sfx[((size_t)bb * UCDIR_STAT_SLOTS + k) * 2 + q];
                 stats_out_host[bb * 2 + q] = (double)acc / UCDIR_STAT_SCALE;

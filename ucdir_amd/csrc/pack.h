@@ -92,6 +92,26 @@ static inline std::vector<bf16_t> pack_conv_ws(const PackedConv& P) {
     return img;
 }
 
+// conv_ws128_kernel (conv_ws128.hip.h), 3x3 conv 128 -> 64 + the block's 1x1 res_conv: from the 10-tap image of pack_conv_res10
+// ([rows][10 * 128], k = tap * 128 + c, tap 9 = res_conv) the A fragments [rw][step j][hh][32 rows][8] bf16 with j = 8 tap + c16
+// (input channels 16 c16 + 8 hh .. + 7), rows permuted as in pack_conv_ws; the res_conv's 8 steps follow the 72 of the 3x3.
+static inline std::vector<bf16_t> pack_conv_ws128(const std::vector<bf16_t>& A10) {
+    const int K10 = 10 * 128, nj = 80;
+    std::vector<bf16_t> img((size_t)2 * nj * 2 * 32 * 8, 0);
+    for (int rw = 0; rw < 2; ++rw)
+        for (int j = 0; j < nj; ++j)
+            for (int hk = 0; hk < 2; ++hk)
+                for (int rho = 0; rho < 32; ++rho) {
+                    const int o = 32 * rw + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+                    const int tap = j >> 3, c0 = 16 * (j & 7) + 8 * hk;
+                    // main image: [rw][72][hh][32][8] first, then the res image [rw][8][hh][32][8] (two separate blocks, see below)
+                    const size_t dst = j < 72 ? ((((size_t)rw * 72 + j) * 2 + hk) * 32 + rho) * 8
+                                              : (size_t)2 * 72 * 2 * 32 * 8 + ((((size_t)rw * 8 + (j - 72)) * 2 + hk) * 32 + rho) * 8;
+                    for (int e = 0; e < 8; ++e) img[dst + e] = A10[(size_t)o * K10 + (size_t)tap * 128 + c0 + e];
+                }
+    return img;
+}
+
 // conv1 of a residual block whose res_conv is fused into it (conv3x3_halo_kernel<64>): the packed rows get a 10th
 // tap block holding the 1x1 res_conv weights (plain bf16, no GroupNorm fold: res_conv sees the raw input).
 // P: pack_conv(conv1) with Kpad == 9*cin; wres: [cout][cin].  Returns [rows_pad][10*cin].
