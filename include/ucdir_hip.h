@@ -110,6 +110,15 @@ int32_t ucdir_sampler_step(float* x_t, const float* eps, const float* noise, int
                            float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
                            void* stream);
 
+/* The same update with its noise generated in registers (ABI 3): element i at step `step` gets the standard normal
+ * Philox4x32-10(key = seed, counter = (i / 4, step)) -> Box-Muller value number i % 4 - a function of (seed, step, i) only, so
+ * every rank of a sharded restoration draws the same noise without a generator or a broadcast, and no noise tensor exists.
+ * ucdir_fill_normal writes the same stream into a buffer (x_T = step 0).  Pointers 16-byte aligned. */
+int32_t ucdir_sampler_step_rng(float* x_t, const float* eps, int64_t n,
+                               float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
+                               uint64_t seed, uint32_t step, void* stream);
+int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, void* stream);
+
 /* ---- introspection (tests / profiling) ---------------------------------------------------
  * Copy the activation a layer produced in the last forward into dst as (B,C,Hc,Wc) fp32 NCHW
  * (Hc, Wc = compute size).  layer = state_dict prefix ("downs.0", "ups.7", "mid.0", ...),

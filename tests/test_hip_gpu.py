@@ -54,10 +54,10 @@ def test_conv_gemm(args):
 
 
 @pytest.mark.parametrize("args", [
-    (3, 32, 48, True, True, 0),       # 16 x 16 tiles, all border tiles, one tile per workgroup; GroupNorm fold + swish
+    (3, 32, 48, True, True, 4096),    # 16 x 16 tiles, all border tiles, one tile per workgroup; GroupNorm fold + swish
     (3, 64, 80, True, True, 7),       # persistent ranges of 8-9 tiles crossing sample boundaries (grid forced to 7 workgroups)
     (2, 48, 48, False, False, 5),     # no fold, no activation (bias only)
-    (2, 288, 288, True, True, 0),     # the network's level-0 size on one workgroup per CU
+    (4, 288, 288, True, True, 0),     # the network's level-0 size on one workgroup per CU (1296 tiles: above the engine's 4-tiles-per-CU threshold)
 ], ids=["even_small", "ranges_cross_samples", "plain", "level0"])
 def test_conv_persistent(args):
     """conv_ws_kernel (3x3, 64 -> 64, persistent, weights in registers): tile ranges, sample crossings, border classes, stats."""
@@ -74,7 +74,7 @@ def test_conv_persistent(args):
 
 
 @pytest.mark.parametrize("args", [
-    (3, 32, 48, 64, 64, 64, 0),        # conv_ws128: 8 x 16 tiles, one tile per workgroup, all border tiles
+    (3, 32, 48, 64, 64, 64, 4096),     # conv_ws128: 8 x 16 tiles, one tile per workgroup, all border tiles
     (3, 64, 80, 64, 64, 64, 7),        # persistent ranges crossing sample boundaries (grid forced to 7 workgroups)
     (2, 288, 288, 64, 64, 64, 0),      # the network's level-0 size (ups.17 / ups.18)
     (2, 40, 56, 128, 64, 64, 0),       # 192 -> 64: conv3x3_halo<64, true> (10th tap)
@@ -102,10 +102,10 @@ def test_akgm(Cc):
 
 
 @pytest.mark.parametrize("args", [
-    (3, 64, 32, 48, 0),      # 16 x 16 tiles, every tile a border tile, one tile per workgroup
+    (3, 64, 32, 48, 4096),   # 16 x 16 tiles, every tile a border tile, one tile per workgroup (grid >= tiles)
     (3, 64, 64, 80, 7),      # persistent ranges of 8-9 tiles that cross sample boundaries (grid forced to 7 workgroups)
     (2, 64, 40, 56, 3),      # ragged tiles (clamped halo, masked stores) inside multi-tile ranges
-    (2, 64, 288, 288, 0),    # the network's level-0 size: 648 tiles on one workgroup per CU
+    (4, 64, 288, 288, 0),    # the network's level-0 size: 1296 tiles on one workgroup per CU (above the 4-tiles-per-CU threshold)
 ], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0"])
 def test_akgm_persistent(args):
     """akgm_ws_kernel (8 channels per group, persistent, weight-stationary): tile ranges, sample crossings, border classes."""
@@ -139,6 +139,42 @@ def test_predictor(shape):
 def test_sampler_step_exact():
     for k, m in C.sampler_step_case().items():
         assert m["max_abs"] < 2e-6, (k, m)       # fp32 point-wise; differences are FMA contraction only
+
+
+def test_in_kernel_noise_is_standard_normal_and_counter_based():
+    """sampler_step_rng / fill_normal (Philox4x32-10 + Box-Muller in the update kernel): N(0, 1) moments over 4 M samples,
+    no correlation between neighbours / steps / seeds, a pure function of (seed, step, element) - independent of how the tensor
+    is split - and the update equals the plain kernel fed with the same noise."""
+    from ucdir_amd.ucdir import fill_normal_, sampler_step_, sampler_step_rng_
+    n = 1 << 22
+    a = fill_normal_(torch.empty(n, device="cuda"), 1234, 3)
+    b = fill_normal_(torch.empty(n, device="cuda"), 1234, 3)
+    assert torch.equal(a, b)
+    x = a.double()
+    m, v = float(x.mean()), float(x.var())
+    sk, ku = float((x ** 3).mean()), float((x ** 4).mean())
+    assert abs(m) < 2.5e-3 and abs(v - 1) < 4e-3 and abs(sk) < 1e-2 and abs(ku - 3) < 3e-2, (m, v, sk, ku)
+    assert float(x.abs().max()) < 6.5                                       # 24-bit uniforms: |z| <= sqrt(2 ln 2^25) = 5.9
+    other_step = fill_normal_(torch.empty(n, device="cuda"), 1234, 4).double()
+    other_seed = fill_normal_(torch.empty(n, device="cuda"), 1235, 3).double()
+    for y in (other_step, other_seed, x.roll(1), x.roll(2), x.roll(4)):
+        assert abs(float((x * y).mean())) < 2.5e-3
+    # counter-based: the second half of a tensor is the second half of the stream, whatever the launch
+    part = fill_normal_(torch.empty(n // 2, device="cuda"), 1234, 3)
+    assert torch.equal(part, a[:n // 2])
+    # tail elements (n not a multiple of 4)
+    t = fill_normal_(torch.empty(1027, device="cuda"), 9, 1)
+    assert torch.equal(t[:1024], fill_normal_(torch.empty(1024, device="cuda"), 9, 1)) and bool(torch.isfinite(t).all())
+    # the fused update == the plain update with the same noise
+    g = torch.Generator().manual_seed(0)
+    xt = torch.randn(2, 3, 64, 64, generator=g).cuda(); eps = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    z = fill_normal_(torch.empty_like(xt), 77, 5)
+    r1 = sampler_step_(xt.clone(), eps, z, 1.7, 1.3, 0.4, 0.6, 0.25)
+    r2 = sampler_step_rng_(xt.clone(), eps, 77, 5, 1.7, 1.3, 0.4, 0.6, 0.25)
+    assert float((r1 - r2).abs().max()) < 2e-6
+    r3 = sampler_step_rng_(xt.clone(), eps, 77, 5, 1.7, 1.3, 0.4, 0.6, 0.0)       # last step: sigma = 0, no noise
+    r4 = sampler_step_(xt.clone(), eps, None, 1.7, 1.3, 0.4, 0.6, 0.0)
+    assert float((r3 - r4).abs().max()) < 2e-6
 
 
 def test_forward_small_vs_oracle_and_golden(golden_dir):
@@ -274,10 +310,11 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
     (2, 288, 288, 128, 64, 1, 0, 0),      # cgemm<64> 1x1 at the 288^2 level (the launch hipcc's packed-f32 code got wrong)
     (4, 288, 288, 64, 64, 3, 1, 0),       # cgemm<64> stride-2 Downsample
     (2, 288, 288, 64, 64, 3, 0, 1),       # conv3x3_halo<64> with the GroupNorm fold
+    (4, 288, 288, 64, 64, 3, 0, 1),       # conv_ws (persistent): per-tile fixed-point partials, partition-independent
     (2, 144, 144, 128, 128, 3, 0, 1),     # conv3x3_halo<128>
     (2, 72, 72, 256, 256, 3, 2, 0),       # Upsample parity launches
     (1, 18, 18, 1024, 512, 3, 0, 1),      # split-K: partial tiles summed in a fixed order by conv_splitk_finish_kernel
-], ids=["1x1_64", "down_64", "halo_64", "halo_128", "up_256", "splitk"])
+], ids=["1x1_64", "down_64", "halo_64", "ws_64", "halo_128", "up_256", "splitk"])
 def test_output_statistics_exact_and_reproducible(args):
     """The (sum, sum of squares) a launch accumulates with fixed-point atomics equal float64 sums of the output it stored
     (up to the bf16 rounding of that output) and are bit-identical from run to run, at the network's real level sizes."""

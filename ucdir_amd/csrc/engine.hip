@@ -457,7 +457,8 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     const bool dual = did_res;                          // conv3x3_halo_kernel<64, true>: second accumulator set
     // 128 -> 64 with the res_conv fused, on 8 x 16 tiles: persistent kernel with one wave per SIMD (conv_ws128.hip.h)
     static const bool use_cws128 = !getenv("UCDIR_NO_CONV_WS128");
-    if (use_cws128 && did_res && w.Aws128 && cin == 128 && x0.C % 8 == 0 && !res && !p.out_nchw && y.H % 8 == 0 && y.W % 16 == 0 && y.C == 64) {
+    if (use_cws128 && did_res && w.Aws128 && cin == 128 && x0.C == 64 && x1 && x1->C == 64 && !res && !p.out_nchw && y.H % 8 == 0 && y.W % 16 == 0 &&
+        y.C == 64 && (g_persist_grid > 0 || (long long)y.B * (y.H / 8) * (y.W / 16) >= 4LL * num_cus())) {
         p.A = w.Aws128; p.alt_A = w.Aws128 + (size_t)2 * 72 * 2 * 32 * 8;
         p.th = 8; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 8;
         const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
@@ -513,7 +514,8 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     // 64 -> 64 on 16 x 16 tiles: persistent weight-stationary kernel (conv_ws.hip.h); UCDIR_NO_CONV_WS falls back
     static const bool use_cws = !getenv("UCDIR_NO_CONV_WS");
     if (use_cws && halo && !upph && !did_res && !dual && w.Aws && !x1 && !res && !p.out_nchw && p.ksplit <= 1 && !p.alt_blocks &&
-        y.H % 16 == 0 && y.W % 16 == 0 && x0.C == 64 && y.C == 64) {
+        y.H % 16 == 0 && y.W % 16 == 0 && x0.C == 64 && y.C == 64 &&
+        (g_persist_grid > 0 || (long long)y.B * (y.H / 16) * (y.W / 16) >= 4LL * num_cus())) {
         p.A = w.Aws; p.th = 16; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 16;
         const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
         const int grid = ntiles < ncu ? ntiles : ncu;
@@ -602,7 +604,10 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const bool att_lds = use_attlds && (w.cg == 16 || w.cg == 32);     // one halo chunk per workgroup: second buffer free
     // persistent weight-stationary kernel (akgm_ws.hip.h): one workgroup per CU walks a range of tiles; UCDIR_NO_WS falls back
     static const bool use_ws = !getenv("UCDIR_NO_WS");
-    const bool ws = pre && use_ws && w.C == 64 && y.H % 16 == 0 && y.W % 16 == 0 && p.th == 16 && p.tw == 16;
+    // (persistent kernels pay from ~4 tiles per CU on: at B = 1, 256^2 - 324 tiles, one or two per workgroup - the one-shot
+    // kernels are 5 % faster per step; the forced grid of the tests bypasses the threshold)
+    const bool ws = pre && use_ws && w.C == 64 && y.H % 16 == 0 && y.W % 16 == 0 && p.th == 16 && p.tw == 16 &&
+                    (g_persist_grid > 0 || (long long)y.B * p.tiles_x * p.tiles_y >= 4LL * num_cus());
     auto launch = [&]() {
         if (ws) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
@@ -1360,6 +1365,36 @@ int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t, 
     hipStream_t st = (hipStream_t)stream;
     if (ctx->use_graph && !g_prof.on) forward_graph(ctx, cond, x_t, noise_level, eps, st);
     else forward(ctx, cond, x_t, noise_level, eps, st);
+    API_END
+}
+
+int32_t ucdir_sampler_step_rng(float* x_t, const float* eps, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
+                               float sigma, uint64_t seed, uint32_t step, void* stream) {
+    API_BEGIN
+    require(x_t && eps, "null argument");
+    require(((uintptr_t)x_t & 15) == 0 && ((uintptr_t)eps & 15) == 0, "ucdir_sampler_step_rng: x_t and eps must be 16-byte aligned");
+    hipPointerAttribute_t pa;
+    HIPC(hipPointerGetAttributes(&pa, x_t));
+    require(pa.type == hipMemoryTypeDevice, "ucdir_sampler_step_rng: x_t is not a device pointer");
+    DevGuard dg(pa.device);
+    long long blocks = ((n + 3) / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sampler_step_rng_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, eps, (long long)n,
+                       c_recip, c_recipm1, coef1, coef2, sigma, (unsigned long long)seed, step);
+    HIPC(hipGetLastError());
+    API_END
+}
+
+int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, void* stream) {
+    API_BEGIN
+    require(x, "null argument");
+    require(((uintptr_t)x & 15) == 0, "ucdir_fill_normal: x must be 16-byte aligned");
+    hipPointerAttribute_t pa;
+    HIPC(hipPointerGetAttributes(&pa, x));
+    require(pa.type == hipMemoryTypeDevice, "ucdir_fill_normal: x is not a device pointer");
+    DevGuard dg(pa.device);
+    long long blocks = ((n + 3) / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (unsigned long long)seed, step);
+    HIPC(hipGetLastError());
     API_END
 }
 

@@ -525,6 +525,71 @@ __global__ void sampler_step_kernel(float* __restrict__ xt, const float* __restr
     }
 }
 
+// Counter-based standard-normal noise for the sampler (SURVEY.md section 7 "RNG"; replaces torch.randn + clone per step on the
+// throughput path - parity tests inject recorded noise instead): Philox4x32-10 (Salmon et al. 2011) keyed by the 64-bit seed,
+// counter = (group of four elements, step) -> four uniforms -> two Box-Muller pairs.  The value of element i at step k depends on
+// (seed, k, i) only: identical on every rank of a sharded restoration, independent of grid size, batch split and launch order.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void normal4(unsigned long long seed, uint32_t step, unsigned long long group, float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), step, 0x55434449u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1): 24 bits, never 0 or 1
+        const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * __logf(u1));
+        z[2 * h] = rad * __builtin_amdgcn_cosf(u2);                                      // v_cos_f32 / v_sin_f32 take revolutions
+        z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
+    }
+}
+// x <- N(0, 1) (x_T of a restoration); n elements, four per thread and counter
+__global__ void fill_normal_kernel(float* __restrict__ x, long long n, unsigned long long seed, uint32_t step) {
+    const long long ng = (n + 3) >> 2;
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        float z[4];
+        normal4(seed, step, (unsigned long long)g, z);
+        if (4 * g + 3 < n) *reinterpret_cast<float4*>(x + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+        else for (int e = 0; e < 4; ++e) if (4 * g + e < n) x[4 * g + e] = z[e];
+    }
+}
+// the sampler update with its noise generated in registers (no noise tensor, no randn / clone launches)
+__global__ void sampler_step_rng_kernel(float* __restrict__ xt, const float* __restrict__ eps, long long n, float c_recip, float c_recipm1,
+                                        float coef1, float coef2, float sigma, unsigned long long seed, uint32_t step) {
+    const long long ng = (n + 3) >> 2;
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sigma != 0.f) normal4(seed, step, (unsigned long long)g, z);
+        if (4 * g + 3 < n) {
+            const float4 x4 = *reinterpret_cast<const float4*>(xt + 4 * g), e4 = *reinterpret_cast<const float4*>(eps + 4 * g);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, es[4] = {e4.x, e4.y, e4.z, e4.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = fminf(fmaxf(c_recip * xs[e] - c_recipm1 * es[e], -1.0f), 1.0f);
+                o[e] = coef1 * x0 + coef2 * xs[e] + z[e] * sigma;
+            }
+            *reinterpret_cast<float4*>(xt + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < n) {
+                    const float x = xt[4 * g + e];
+                    const float x0 = fminf(fmaxf(c_recip * x - c_recipm1 * eps[4 * g + e], -1.0f), 1.0f);
+                    xt[4 * g + e] = coef1 * x0 + coef2 * x + z[e] * sigma;
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2x2 max pooling (predictor, model/ucdir.py:317,363): zero-bordered NHWC bf16 in and out.
 // ------------------------------------------------------------------------------------------------

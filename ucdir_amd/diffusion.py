@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .ucdir import UNetSeeInDark, sampler_step_
+from .ucdir import UNetSeeInDark, fill_normal_, sampler_step_, sampler_step_rng_
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
@@ -118,6 +118,13 @@ class GaussianDiffusion(nn.Module):
     def _start_noise(self, device):
         """(Re)seed the rank-identical generator at the start of a sampling loop."""
         self._gen = None
+        # p_sample_loop draws its noise INSIDE the update kernel (counter-based Philox keyed by (seed, step, element),
+        # csrc/misc.hip.h): seed = noise_seed + image offset when set (identical on every rank), else a fresh 63-bit draw from
+        # torch's CPU generator (torch.manual_seed still makes a run reproducible).  Injected noise (noise_source) bypasses it.
+        if self.noise_seed is not None:
+            self._kseed = int(self.noise_seed) + 1000003 * int(self.noise_index)
+        else:
+            self._kseed = int(torch.randint(0, 2 ** 62, (1,)).item())
         if self.noise_seed is not None and self.noise_source is None:
             # noise_index (set by the caller per image, e.g. the dataset index) keeps the noise of different images
             # independent while every rank of a sharded restoration still draws the identical sequence
@@ -168,10 +175,16 @@ class GaussianDiffusion(nn.Module):
                 self._graph_bufs = bufs
             _, cond, img, eps_buf, lvl = bufs
             cond.copy_(x)
-            img.copy_(self._noise(x, 0))
+            if self.noise_source is not None:
+                img.copy_(self._noise(x, 0))
+            else:
+                fill_normal_(img, self._kseed, 0)
         else:
             cond = x
-            img = self._noise(x, 0).clone()                   # x_t: ONE buffer, updated in place
+            if self.noise_source is not None:
+                img = self._noise(x, 0).clone()               # x_t: ONE buffer, updated in place
+            else:
+                img = fill_normal_(torch.empty_like(x), self._kseed, 0)
             eps_buf = torch.empty_like(img)
             lvl = torch.empty((B, 1), dtype=torch.float32, device=x.device)
         ret = [x]
@@ -180,8 +193,11 @@ class GaussianDiffusion(nn.Module):
             level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
             lvl.fill_(level)
             eps = self._eps(cond, img, lvl, guide, out=eps_buf)
-            noise = self._noise(img, k) if i > 0 else None
-            sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
+            if self.noise_source is not None:
+                noise = self._noise(img, k) if i > 0 else None
+                sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
+            else:                                             # noise of (seed, step k, element) generated in the update kernel
+                sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
             if i > 0:
                 k += 1
             if i % sample_inter == 0:

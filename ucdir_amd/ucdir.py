@@ -304,6 +304,28 @@ def sampler_step_(x_t, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma):
     return x_t
 
 
+def sampler_step_rng_(x_t, eps, seed, step, c_recip, c_recipm1, coef1, coef2, sigma):
+    """The same update with the noise of (seed, step, element) generated inside the kernel (no noise tensor)."""
+    L = _lib.load()
+    if not (x_t.is_cuda and x_t.is_contiguous() and x_t.dtype == torch.float32):
+        raise _lib.UcdirError("sampler_step_rng_ needs contiguous fp32 CUDA tensors")
+    eps = eps.contiguous()
+    if not (eps.is_cuda and eps.dtype == torch.float32 and eps.numel() == x_t.numel()):
+        raise _lib.UcdirError("sampler_step_rng_: eps must be an fp32 CUDA tensor shaped like x_t")
+    _lib.check(L.ucdir_sampler_step_rng(_ptr(x_t), _ptr(eps), x_t.numel(), float(c_recip), float(c_recipm1), float(coef1),
+                                        float(coef2), float(sigma), int(seed) & (2 ** 64 - 1), int(step), _stream_ptr(x_t.device)))
+    return x_t
+
+
+def fill_normal_(x, seed, step=0):
+    """x <- N(0, 1) from the sampler's counter-based generator (x_T = step 0 of the stream the update kernel draws from)."""
+    L = _lib.load()
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+        raise _lib.UcdirError("fill_normal_ needs a contiguous fp32 CUDA tensor")
+    _lib.check(L.ucdir_fill_normal(_ptr(x), x.numel(), int(seed) & (2 ** 64 - 1), int(step), _stream_ptr(x.device)))
+    return x
+
+
 class UNetSeeInDark(nn.Module):
     """Initial-restoration predictor (model/ucdir.py:310-416) on the HIP engine; parameter names and
     shapes match the reference, there is no PyTorch forward."""
