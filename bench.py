@@ -111,12 +111,14 @@ def roofline_record(rows, whole_tflops=None):
             traffic = None
     roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_source": "stored: PMC FETCH_SIZE / WRITE_SIZE per launch of the profiled build (profiles/traffic.json), not measured in this run",
             "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "flops_per_launch": d["flops"] / d["launches"], "bytes_per_launch": d["bytes"] / d["launches"],
             "all_kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
                              "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)} for r in rows]}
     if whole_tflops is not None:
         roof["forward_tflops_whole"] = whole_tflops
+        roof["forward_frac_whole"] = whole_tflops / MFMA_BF16_PEAK_TFLOPS      # all launches of a forward against the dense bf16 peak
     return roof
 
 

@@ -29,6 +29,12 @@ def bench_name(k):
         return "akgm_halo"                          # <true> / <false> instantiations share one bench row
     if "akgm_pre_kernel" in k:
         return "akgm_pre"
+    if "akgm_ws_kernel" in k:
+        return "akgm_ws"
+    if "conv_ws128_kernel" in k:
+        return "conv_ws<128->64>+res"
+    if "conv_ws_kernel" in k:
+        return "conv_ws<64>"
     m = re.search(r"conv3x3_halo_kernel<(\d+)(?:, (true|false))?>", k)
     if m:
         # <128> / <64> also carry the parity-decomposed Upsample launches; <64, true> = conv1 + fused res_conv
