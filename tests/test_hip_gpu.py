@@ -106,9 +106,12 @@ def test_akgm(Cc):
     (3, 64, 64, 80, 7),      # persistent ranges of 8-9 tiles that cross sample boundaries (grid forced to 7 workgroups)
     (2, 64, 40, 56, 3),      # ragged tiles (clamped halo, masked stores) inside multi-tile ranges
     (4, 64, 288, 288, 0),    # the network's level-0 size: 1296 tiles on one workgroup per CU (above the 4-tiles-per-CU threshold)
-], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0"])
+    (3, 128, 32, 48, 4096),  # 16 channels per group: one 64-channel plane per workgroup, one tile per workgroup pair
+    (3, 128, 64, 80, 14),    # ... ranges of 8-9 tiles that cross sample boundaries (7 workgroup pairs)
+    (8, 128, 144, 144, 0),   # ... the network's 144^2 level on one workgroup per CU
+], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0", "cg16_small", "cg16_ranges", "cg16_level1"])
 def test_akgm_persistent(args):
-    """akgm_ws_kernel (8 channels per group, persistent, weight-stationary): tile ranges, sample crossings, border classes."""
+    """akgm_ws_kernel (8 | 16 channels per group, persistent, weight-stationary): tile ranges, sample crossings, border classes."""
     B, Cc, H, W, grid = args
     L = C.ulib.load()
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))

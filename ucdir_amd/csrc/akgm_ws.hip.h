@@ -68,11 +68,21 @@ __device__ __forceinline__ u32x4_t asm_load16(const void* base, unsigned voff) {
 #define WS_PK 0                                                   // 1: modulation sum on v_pk_fma_f32 - half the issue slots, but measured 2 % SLOWER (same box, 198 vs 194 us): packed fp32 beside the partner wave's MFMAs is an anti-lever (cdna guide, price list)
 #endif
 
+// CG = 8 : C = 64, wave = group (above).
+// CG = 16: C = 128 (the 144^2 level).  A group's 128 rows x K = 144 are 144 A registers - too many next to 64 accumulators -
+//          so a workgroup owns ONE 64-channel plane of the tensor (ch = lid & 1; the two workgroups of a pair walk the same tile
+//          range and share G and the pixel lines in their XCD's L2) and wave w owns output features 64 ch + 8 w .. + 7: the
+//          64 rows of row half w & 1 of group 4 ch + w / 2, K = 9 taps x 16 channels = 72 A registers.  Everything else - halo
+//          plane in LDS, fold-table slice [9][512], epilogue, 16-byte stores - is the CG = 8 kernel with a 256-byte pixel.
+template <int CG>
 __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) {
+    constexpr int NK = (CG == 8) ? 5 : 9;                          // 16-wide k steps
+    constexpr int NCH = CG / 8;                                    // 64-channel planes per pixel
+    constexpr int CPX = 64 * NCH;                                  // channels per pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = group
-    const int U = wave >> 1, wm = wave & 1;                       // unit / row half of pack_akgm_pre
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = group (CG 8) | half a group (CG 16)
+    const int wm = wave & 1;                                      // row half of pack_akgm_pre's unit
     // lane -> pixel of a 32-pixel MFMA tile (two tile rows): row l31 / 16, column (l31 % 16) ^ 8 in the second row: with the
     // 24-pixel pitch every ds_read_b128 lane group then reads 16 different 16-byte slots (the plain mapping was 2-way everywhere)
     const int prow = l31 >> 4, pcol = (l31 & 15) ^ (prow << 3);
@@ -92,24 +102,27 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
     WS_STAMP();
     const int tps = p.tiles_x * p.tiles_y;
     const int T = p.nbatch * tps;
-    const int t_beg = (int)((long long)lid * T / (int)gridDim.x), t_end = (int)((long long)(lid + 1) * T / (int)gridDim.x);
+    const int ch = (NCH == 2) ? (lid & 1) : 0;                     // this workgroup's channel plane
+    const int rid = (NCH == 2) ? (lid >> 1) : lid, nrange = (int)gridDim.x / NCH;
+    const int t_beg = (int)((long long)rid * T / nrange), t_end = (int)((long long)(rid + 1) * T / nrange);
     if (t_beg >= t_end) return;
+    const int U = (NCH == 2 ? 4 * ch : 0) + (wave >> 1);           // unit of pack_akgm_pre (CG 8: 16 features of two groups, CG 16: one group)
 
     // ---- this wave's weights: A fragments of pack_akgm_pre's image, resident for the whole launch -------------------
-    bf16x8_t af[2][5];
+    bf16x8_t af[2][NK];
     {
-        const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + (long long)U * AkPre<8>::A_UNIT + (hh * 128 + wm * 64 + l31) * 16;
+        const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + (long long)U * AkPre<CG>::A_UNIT + (hh * 128 + wm * 64 + l31) * 16;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) af[tm][j] = *reinterpret_cast<const bf16x8_t*>(Ab + j * 4096 + tm * 512);
+            for (int j = 0; j < NK; ++j) af[tm][j] = *reinterpret_cast<const bf16x8_t*>(Ab + j * 4096 + tm * 512);
     }
     // the compiler's wait for these loads goes HERE (an asm statement reading them), not in front of their first use inside the
     // tile loop, where a vmcnt(0) per pixel pair would drain the next tile's DMA and the previous pair's store
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(af[tm][j]));
+        for (int j = 0; j < NK; ++j) asm volatile("" : "+v"(af[tm][j]));
 
     // ---- tile-invariant lane constants ---------------------------------------------------------------------------------
     // halo piece k = r * 3 + c3 (row r, pixel columns 8 c3 .. 8 c3 + 7; columns >= 18 do not exist): wave w stages pieces
@@ -120,20 +133,23 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         int k = i * 8 + wave; k = k > 53 ? 53 : k;
         const int r = k / 3, col = (k - 3 * r) * 8 + (lane >> 3);
         const int hp = r * AkWs::PITCH + col;
-        hrel[i] = col < 18 ? (r * p.Wp + col) * 64 + (((lane & 7) ^ ((hp >> 1) & 7)) << 3) : -1;
+        hrel[i] = col < 18 ? (r * p.Wp + col) * CPX + 64 * ch + (((lane & 7) ^ ((hp >> 1) & 7)) << 3) : -1;
     }
     const int grel = (((wave * 32 + (lane >> 1)) >> 4) * p.W + ((lane >> 1) & 15)) * 8 + (lane & 1) * 4;   // guide piece `wave`: pixel 32 wave + lane / 2
-    unsigned bj0[5];                               // B fragment of k step j, px-tile 0, buffer 0: LDS byte address
+    unsigned bj[NK];                               // B fragment of k step j, px-tile 0, current buffer: LDS byte address
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int t = (2 * j + hh > 8) ? 8 : 2 * j + hh;               // tap 2j (lanes 0-31) | 2j + 1 (lanes 32-63; tap 9 has zero weights: reads tap 8)
+    for (int j = 0; j < NK; ++j) {
+        // CG 8 : tap 2j (lanes 0-31) | 2j + 1 (lanes 32-63; tap 9 has zero weights: reads tap 8), the group's one 16-byte chunk
+        // CG 16: tap j, the group's chunk pair 2 (w / 2) + lane half
+        const int t = (CG == 8) ? ((2 * j + hh > 8) ? 8 : 2 * j + hh) : j;
+        const int chunk = (CG == 8) ? wave : 2 * (wave >> 1) + hh;
         const int hp = (prow + t / 3) * AkWs::PITCH + pcol + t % 3;
-        bj0[j] = (hp << 7) | ((wave ^ ((hp >> 1) & 7)) << 4);
+        bj[j] = ((hp << 7) | ((chunk ^ ((hp >> 1) & 7)) << 4)) + AkWs::HALO;      // (flipped to buffer 0 at the top of the first tile)
     }
-    const unsigned tc_lane = AkWs::OFF_TCS + 4 * 8 * (16 * U + 8 * wm + 2 * hh);   // + 128 tm + 2048 cls: first of this lane's 16 table entries
+    const unsigned tc_lane = AkWs::OFF_TCS + 4 * 8 * (8 * wave + 2 * hh);   // + 128 tm + 2048 cls: first of this lane's 16 table entries
     const unsigned att_lane = AkWs::OFF_ATT + (prow * 16 + pcol) * 32;              // + 1024 q: this lane's pixel of px-tile q
-    const unsigned rel2 = (unsigned)((((lane >> 4) + 1) * p.Wp + ((lane & 15) ^ (((lane >> 4) & 1) << 3)) + 1) * 64 + wave * 8) * 2;   // store item: pixel row lane / 16 + 4 pp, column as pcol, features 8 g ..
-    const long long pp_step = (long long)4 * p.Wp * 64 * 2;            // bytes between the store items of consecutive pairs
+    const unsigned rel2 = (unsigned)((((lane >> 4) + 1) * p.Wp + ((lane & 15) ^ (((lane >> 4) & 1) << 3)) + 1) * CPX + 64 * ch + wave * 8) * 2;   // store item: pixel row lane / 16 + 4 pp, column as pcol, features 64 ch + 8 w ..
+    const long long pp_step = (long long)4 * p.Wp * CPX * 2;           // bytes between the store items of consecutive pairs
 
     int b, ty, tx;                                 // tile t
     {
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         ty = r / p.tiles_x; tx = r - ty * p.tiles_x;
     }
     auto issue_tile = [&](int nb, int nty, int ntx, int buf) {
-        const bf16_t* hb = p.h + (long long)nb * p.h_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * 64;
+        const bf16_t* hb = p.h + (long long)nb * p.h_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * CPX;
         unsigned char* hd = smem + buf * AkWs::HALO;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             for (int i = 0; i < 3; ++i) {
                 const int pc = i * 8 + wave;
                 if (pc < 18)
-                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + (long long)b * 9 * 512 + pc * 256 + lane * 4),
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + (pc >> 1)) * (512 * NCH) + 512 * ch + (pc & 1) * 256 + lane * 4),
                                                      (LDS_AS void*)(smem + AkWs::OFF_TCS + pc * 1024), 16, 0, 0);
             }
             rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             asm volatile("s_barrier" ::: "memory");
         }
         const bool interior = ty > 0 && tx > 0 && ty + 1 < p.tiles_y && tx + 1 < p.tiles_x;
-        const long long tile_el = (long long)(ty * 16 * p.Wp + tx * 16) * 64;
+        const long long tile_el = (long long)(ty * 16 * p.Wp + tx * 16) * CPX;
         const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.res + (long long)b * p.res_bstride + tile_el);
         unsigned char* outb = reinterpret_cast<unsigned char*>(p.out + (long long)b * p.out_bstride + tile_el);
 
@@ -213,10 +229,8 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         u32x4_t rv3 = asm_load16(resb + 3 * pp_step, rel2);
         WS_STAMP();                                                 // residuals requested, next tile's DMA issued
 
-        const unsigned bufh = buf * AkWs::HALO;
-        unsigned bj[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) bj[j] = bj0[j] + bufh;
+        for (int j = 0; j < NK; ++j) bj[j] = buf ? bj[j] + AkWs::HALO : bj[j] - AkWs::HALO;     // in place: NK registers, not 2 NK
         const unsigned attq = att_lane + buf * AkWs::ATT;
 
         float s1 = 0.f, s2 = 0.f;
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             // ---- K loop: 5 steps of two taps x 8 channels; B fragments from the halo, A fragments from registers ------
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < NK; ++j) {
                 bf16x8_t bfr[2];
 #pragma unroll
                 for (int tp = 0; tp < 2; ++tp) bfr[tp] = *reinterpret_cast<const bf16x8_t*>(smem + bj[j] + (2 * pp + tp) * AkWs::QSTEP);

@@ -129,7 +129,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
-    if (P.cg == 8) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
+    if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
     return W;
 }
 
@@ -180,7 +180,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv3x3_halo_kernel<64, true>, hc_lds_bytes<64>());
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
-    set_lds_attr(akgm_ws_kernel, AkWs::LDS);
+    set_lds_attr(akgm_ws_kernel<8>, AkWs::LDS); set_lds_attr(akgm_ws_kernel<16>, AkWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
@@ -608,11 +608,20 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     // kernels are 5 % faster per step; the forced grid of the tests bypasses the threshold)
     const bool ws = pre && use_ws && w.C == 64 && y.H % 16 == 0 && y.W % 16 == 0 && p.th == 16 && p.tw == 16 &&
                     (g_persist_grid > 0 || (long long)y.B * p.tiles_x * p.tiles_y >= 4LL * num_cus());
+    // 16 channels per group (C = 128): the same kernel, one 64-channel plane per workgroup
+    static const bool use_ws16 = !getenv("UCDIR_NO_WS16");
+    const bool ws16 = use_ws && use_ws16 && w.Apre != nullptr && w.cg == 16 && w.C == 128 && y.H % 16 == 0 && y.W % 16 == 0 &&
+                      (g_persist_grid > 0 || (long long)y.B * (y.H / 16) * (y.W / 16) * 2 >= 4LL * num_cus());
+    if (ws16) { p.A = w.Apre; p.th = 16; p.tw = 16; p.tiles_x = y.W / 16; p.tiles_y = y.H / 16; }
     auto launch = [&]() {
         if (ws) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
             const int grid = ntiles < ncu ? ntiles : ncu;
-            hipLaunchKernelGGL(akgm_ws_kernel, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
+            hipLaunchKernelGGL(akgm_ws_kernel<8>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
+        } else if (ws16) {
+            const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus() & ~1;
+            const int grid = 2 * ntiles < ncu ? 2 * ntiles : ncu;            // workgroup pairs: (tile range, channel plane)
+            hipLaunchKernelGGL(akgm_ws_kernel<16>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
         } else if (pre) {
             hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
         } else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
@@ -635,7 +644,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = ws ? 113 : (pre ? 112 : 111); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        ProfEntry e; e.key = ws ? 113 : (ws16 ? 114 : (pre ? 112 : 111)); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
         e.dH = y.H; e.dW = y.W; e.dCin = w.C; e.dCout = w.C;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
