@@ -22,7 +22,30 @@
 //     accumulated in 64-bit integers, so the totals do not depend on how tiles are dealt to workgroups (bit-identical
 //     for any batch size or CU count) and no barrier is needed for them.
 #pragma once
+#include <type_traits>
 #include "akgm_pre.hip.h"
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the body sees its index as a constant expression
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// LDS fragment read the compiler does not count (cdna guide 5.7 form iii): with hipcc's own bookkeeping the K loop of this
+// one-wave-per-SIMD kernel drained the LDS queue (lgkmcnt(0)) every second step - 44 instead of 32 cycles per MFMA
+template <int OFF>
+__device__ __forceinline__ void lds_read16_asm(bf16x8_t& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16f_asm(f32x4_t& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_asm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);                             // no MFMA is scheduled above the wait that covers its operand
+}
+
 
 struct AkWs {
     static constexpr int PITCH = 24;                              // halo pixels per LDS row (18 used)
@@ -234,7 +257,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         const unsigned attq = att_lane + buf * AkWs::ATT;
 
         float s1 = 0.f, s2 = 0.f;
-        auto do_pair = [&](const int pp, u32x4_t& rvp, auto wait_res) {
+        auto do_pair = [&](auto ppc, u32x4_t& rvp, auto wait_res) {
+            constexpr int PP = decltype(ppc)::value;
+            const int pp = PP;
             // ---- accumulators start at the fold constants of the pixel's border class --------------------------------
             f32x16_t acc[2][2];
 #pragma unroll
@@ -255,27 +280,47 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
                     }
             }
             // ---- K loop: 5 steps of two taps x 8 channels; B fragments from the halo, A fragments from registers ------
+            // software pipeline by hand: B fragments by inline-asm ds_read_b128 with counted lgkmcnt (hipcc's own bookkeeping put
+            // a full lgkmcnt(0) in front of every step - or, with a second register set, every second step - ~100 idle
+            // matrix-core cycles each): the fragments of step j + 1 are requested in front of the MFMAs of step j, the pixel's
+            // modulation weights in front of the last two steps instead of behind the loop
+            bf16x8_t bfr[2][2];
+            f32x4_t a0[2], a1[2];
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fold constants; nothing of the compiler's own is queued behind this
+            static_for<0, 2>([&](auto tpc) { constexpr int tp = decltype(tpc)::value; lds_read16_asm<(2 * PP + tp) * AkWs::QSTEP>(bfr[0][tp], bj[0]); });
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < NK; ++j) {
-                bf16x8_t bfr[2];
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp) bfr[tp] = *reinterpret_cast<const bf16x8_t*>(smem + bj[j] + (2 * pp + tp) * AkWs::QSTEP);
+            static_for<0, NK>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + 1 < NK) {
+                    static_for<0, 2>([&](auto tpc) { constexpr int tp = decltype(tpc)::value; lds_read16_asm<(2 * PP + tp) * AkWs::QSTEP>(bfr[(j + 1) & 1][tp], bj[j + 1]); });
+                }
+                if constexpr (j == NK - 2) {
+                    static_for<0, 2>([&](auto tpc) {
+                        constexpr int tp = decltype(tpc)::value;
+                        lds_read16f_asm<(2 * PP + tp) * 1024>(a0[tp], attq);
+                        lds_read16f_asm<(2 * PP + tp) * 1024 + 16>(a1[tp], attq);
+                    });
+                }
+                // reads younger than step j's: step j + 1's two, and at j = NK - 2 the four weight reads; at the last step the
+                // weight reads are younger than nothing that is needed -> they are waited for behind the loop
+                constexpr int younger = (j + 1 < NK ? 2 : 0) + (j == NK - 2 ? 4 : 0) + (j == NK - 1 ? 4 : 0);
+                lgkm_wait_asm<(j == NK - 1) ? 4 : younger>();
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                     for (int tp = 0; tp < 2; ++tp)
-                        acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][j], bfr[tp], acc[tm][tp], 0, 0, 0);
-            }
+                        acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][j], bfr[j & 1][tp], acc[tm][tp], 0, 0, 0);
+            });
+            lgkm_wait_asm<0>();
             __builtin_amdgcn_s_setprio(0);
             WS_STAMP();                                             // K loop done
             // ---- modulation sum in registers: vq[tm][q][tp] = feature 8 g + 4 tm + 2 hh + q of pixel tp ----------------
             float vq[2][2][2];
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
-                const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(smem + attq + (2 * pp + tp) * 1024), a1 = *reinterpret_cast<const f32x4_t*>(smem + attq + (2 * pp + tp) * 1024 + 16);
 #if WS_PK
-                const f32x2_t at2[4] = {{a0[0] * aw[0], a0[1] * aw[1]}, {a0[2] * aw[2], a0[3] * aw[3]}, {a1[0] * aw[4], a1[1] * aw[5]}, {a1[2] * aw[6], a1[3] * aw[7]}};
+                const f32x2_t at2[4] = {{a0[tp][0] * aw[0], a0[tp][1] * aw[1]}, {a0[tp][2] * aw[2], a0[tp][3] * aw[3]}, {a1[tp][0] * aw[4], a1[tp][1] * aw[5]}, {a1[tp][2] * aw[6], a1[tp][3] * aw[7]}};
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
                         vq[tm][q][tp] = rstd * (sa[0] + sa[1]);
                     }
 #else
-                const float att[8] = {a0[0] * aw[0], a0[1] * aw[1], a0[2] * aw[2], a0[3] * aw[3], a1[0] * aw[4], a1[1] * aw[5], a1[2] * aw[6], a1[3] * aw[7]};
+                const float att[8] = {a0[tp][0] * aw[0], a0[tp][1] * aw[1], a0[tp][2] * aw[2], a0[tp][3] * aw[3], a1[tp][0] * aw[4], a1[tp][1] * aw[5], a1[tp][2] * aw[6], a1[tp][3] * aw[7]};
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -327,10 +372,10 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             WS_STAMP();                                             // pair stored
             __builtin_amdgcn_sched_barrier(0);                       // pairs are not interleaved by the compiler (register pressure)
         };
-        do_pair(0, rv0, [&]() { WS_WAIT_RES(3, rv0); });
-        do_pair(1, rv1, [&]() { WS_WAIT_RES(2, rv1); });
-        do_pair(2, rv2, [&]() { WS_WAIT_RES(1, rv2); });
-        do_pair(3, rv3, [&]() { WS_WAIT_RES(0, rv3); });
+        do_pair(std::integral_constant<int, 0>{}, rv0, [&]() { WS_WAIT_RES(3, rv0); });
+        do_pair(std::integral_constant<int, 1>{}, rv1, [&]() { WS_WAIT_RES(2, rv1); });
+        do_pair(std::integral_constant<int, 2>{}, rv2, [&]() { WS_WAIT_RES(1, rv2); });
+        do_pair(std::integral_constant<int, 3>{}, rv3, [&]() { WS_WAIT_RES(0, rv3); });
         S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
         b = nb; ty = nty; tx = ntx;
     }

@@ -19,23 +19,6 @@
 #include <type_traits>
 #include "conv_ws.hip.h"
 
-// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the body sees its index as a constant expression
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-// LDS fragment read the compiler does not count (cdna guide 5.7 form iii): with hipcc's own bookkeeping the K loop of this
-// one-wave-per-SIMD kernel drained the LDS queue (lgkmcnt(0)) every second step - 44 instead of 32 cycles per MFMA
-template <int OFF>
-__device__ __forceinline__ void lds_read16_asm(bf16x8_t& v, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait_asm() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);                             // no MFMA is scheduled above the wait that covers its operand
-}
-
 struct CvWs128 {
     static constexpr int PITCH = 24;
     static constexpr int PLANE = 10 * PITCH * 128;                // 30,720: [10][24][64 ch] bf16 of one input tensor
