@@ -13,8 +13,9 @@
 //   * halo in LDS: [18 rows][24-pixel pitch][64 ch] bf16, 16-byte chunk XOR (pixel >> 1) & 7 (on the DMA's source
 //     side).  The pitch makes a 32-pixel MFMA tile (two tile rows) exactly 48 pixels = 6,144 bytes and leaves the
 //     swizzle unchanged, so every B fragment address is one of five per-lane registers + an immediate;
-//   * the halo and the guide weights G of tile t + 1 are requested by LDS-DMA at the top of tile t into the second
-//     buffer: ONE barrier per tile and no vmcnt in front of it (see the residual order below);
+//   * the halo and the guide weights G of tile t + 1 are requested by LDS-DMA during tile t into the second buffer, two or
+//     three pieces per pixel pair (all at the tile top: every wave stalls at issue for thousands of cycles): ONE barrier
+//     per tile and no vmcnt in front of it (see the residual order below);
 //   * GroupNorm-fold table Tc[9][512] of the current sample resident in LDS (reloaded when the range crosses a
 //     sample); accumulators start at it, modulation sum / half-wave exchange / swish / residual / 16-byte store as in
 //     akgm_pre.hip.h;
@@ -55,7 +56,8 @@ struct AkWs {
     static constexpr int OFF_ATT = 2 * HALO;
     static constexpr int OFF_TCS = OFF_ATT + 2 * ATT;             // [9][512] fp32
     static constexpr int OFF_SCAL = OFF_TCS + 9 * 512 * 4;
-    static constexpr int LDS = OFF_SCAL + 128;                    // 145,536: one workgroup per CU
+    static constexpr int OFF_RES = OFF_SCAL + 128;                // residual staging: [8 waves][2 slots][64 lanes x 16 B]
+    static constexpr int LDS = OFF_RES + 8 * 2 * 1024;            // 161,920 of 163,840: one workgroup per CU
     static constexpr int NDMA = 8;                                // LDS-DMA instructions per wave and tile (7 halo pieces + 1 guide piece)
 };
 
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
 #else
 #define WS_STAMP() do {} while (0)
 #endif
+#ifdef WS_FINE_STAMPS                                              // store-phase anatomy: behind the wait | DMA issued | residual requested
+#define WS_STAMP2() WS_STAMP()
+#else
+#define WS_STAMP2() do {} while (0)
+#endif
     WS_STAMP();
     const int tps = p.tiles_x * p.tiles_y;
     const int T = p.nbatch * tps;
@@ -171,7 +178,6 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
     }
     const unsigned tc_lane = AkWs::OFF_TCS + 4 * 8 * (8 * wave + 2 * hh);   // + 128 tm + 2048 cls: first of this lane's 16 table entries
     const unsigned att_lane = AkWs::OFF_ATT + (prow * 16 + pcol) * 32;              // + 1024 q: this lane's pixel of px-tile q
-    const unsigned rel2 = (unsigned)((((lane >> 4) + 1) * p.Wp + ((lane & 15) ^ (((lane >> 4) & 1) << 3)) + 1) * CPX + 64 * ch + wave * 8) * 2;   // store item: pixel row lane / 16 + 4 pp, column as pcol, features 64 ch + 8 w ..
     const long long pp_step = (long long)4 * p.Wp * CPX * 2;           // bytes between the store items of consecutive pairs
 
     int b, ty, tx;                                 // tile t
@@ -180,18 +186,49 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         const int r = t_beg - b * tps;
         ty = r / p.tiles_x; tx = r - ty * p.tiles_x;
     }
-    auto issue_tile = [&](int nb, int nty, int ntx, int buf) {
-        const bf16_t* hb = p.h + (long long)nb * p.h_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * CPX;
-        unsigned char* hd = smem + buf * AkWs::HALO;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
+    // DMA piece i of a tile (i < 7: this wave's halo piece 8 i + wave; 7: its guide piece) into buffer `buf`
+    auto issue_piece = [&](auto ic, const bf16_t* hb, const float* gb, int buf) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < 7) {
             int k = i * 8 + wave; k = k > 53 ? 53 : k;
-            if (hrel[i] >= 0) stage16(hb + hrel[i], hd + k * 1024, lane);
+            if (hrel[i] >= 0) stage16(hb + hrel[i], smem + buf * AkWs::HALO + k * 1024, lane);
+        } else {
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gb + grel), (LDS_AS void*)(smem + AkWs::OFF_ATT + buf * AkWs::ATT + wave * 1024), 16, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.G + (long long)nb * p.g_bstride + (long long)(nty * 16 * p.W + ntx * 16) * 8 + grel),
-                                         (LDS_AS void*)(smem + AkWs::OFF_ATT + buf * AkWs::ATT + wave * 1024), 16, 0, 0);
     };
-    issue_tile(b, ty, tx, 0);
+    auto halo_base = [&](int nb, int nty, int ntx) { return p.h + (long long)nb * p.h_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * CPX; };
+    auto guide_base = [&](int nb, int nty, int ntx) { return p.G + (long long)nb * p.g_bstride + (long long)(nty * 16 * p.W + ntx * 16) * 8; };
+    auto res_base = [&](int nb, int nty, int ntx) {
+        return reinterpret_cast<const unsigned char*>(p.res + (long long)nb * p.res_bstride + (long long)(nty * 16 * p.Wp + ntx * 16) * CPX);
+    };
+    {
+        const bf16_t* hb = halo_base(b, ty, tx);
+        const float* gb = guide_base(b, ty, tx);
+        static_for<0, 8>([&](auto ic) { issue_piece(ic, hb, gb, 0); });
+    }
+    // Output / residual staging (AkWs::OFF_RES): [2 slots][64 pixels of a pair][128 B = this plane's 64 channels], 16-byte
+    // chunk XOR (pixel & 7).  A wave owns 16 bytes (its 8 features) of EVERY pixel: stored straight from registers that is 64
+    // sixteen-byte pieces of 64 different 128-byte lines per instruction - the stores alone cost 50 of 186 us per level-0 launch
+    // (measured with the store removed), the residual loads of the same shape 20 more.  Here wave w moves whole lines instead:
+    //   residual of pair q + 2: LDS-DMA of pixels 8 w .. 8 w + 7 (1 KB, eight full lines) into the slot, one pair ahead;
+    //   epilogue of pair q   : lane = pixel reads its residual chunk from the slot and writes the result back in place;
+    //   sync S(q)            : own DMA landed (counted vmcnt), own chunks written (lgkmcnt), s_barrier;
+    //   behind S(q)          : lane = (pixel 8 w + j, chunk c) reads the finished lines and stores 1 KB = eight full lines.
+    // S(3) is also the tile barrier (all K loops of the tile done, all pieces of the next tile landed).
+    const unsigned stg_lane = AkWs::OFF_RES + lane * 128 + ((wave ^ (lane & 7)) << 4);      // epilogue: pixel = lane, this wave's chunk
+    const unsigned line_lane = AkWs::OFF_RES + wave * 1024 + lane * 16;                      // line mover: lane-linear
+    unsigned rel3;                                                                           // line mover: byte offset of (pixel 8 w + lane / 8, logical chunk) in the tile
+    {
+        const int j = lane >> 3, c = lane & 7, row = wave >> 1, col = (8 * (wave & 1) + j) ^ ((row & 1) << 3);
+        rel3 = (unsigned)(((row + 1) * p.Wp + col + 1) * CPX + 64 * ch) * 2 + ((c ^ j) << 4);
+    }
+    auto issue_res = [&](const unsigned char* src, int slot) {
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + rel3), (LDS_AS void*)(smem + AkWs::OFF_RES + slot * 8192 + wave * 1024), 16, 0, 0);
+    };
+    issue_res(res_base(b, ty, tx), 0);
+    issue_res(res_base(b, ty, tx) + pp_step, 1);
+    HC_WAIT(0);
+    asm volatile("s_barrier" ::: "memory");
 
     int b_cur = -1;
     float rstd = 1.f, aw[8];
@@ -204,9 +241,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         const int buf = (t - t_beg) & 1;
         const bool last = t + 1 == t_end;
         WS_STAMP();                                                 // tile top
-        // this tile's halo / guide pieces were issued one tile ago and have landed: this wave passed vmcnt(0) in pair 3
-        if (t == t_beg) { HC_WAIT(0); }
-        asm volatile("s_barrier" ::: "memory");
+        // (the barrier that opens this tile is S(3) of the previous one - or the one in front of the loop)
         WS_STAMP();                                                 // behind the barrier
         if (b != b_cur) {                                           // range enters a new sample: its fold table, rstd, attw
             if (b_cur >= 0 && p.stats_out) {
@@ -233,31 +268,33 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.res + (long long)b * p.res_bstride + tile_el);
         unsigned char* outb = reinterpret_cast<unsigned char*>(p.out + (long long)b * p.out_bstride + tile_el);
 
-        // Store item pp of this lane: pixel 64 pp + lane, features 8 g .. 8 g + 7.  Its residual (16 bytes) is requested by inline
-        // asm (hipcc neither unpacks it right behind the load nor drains the DMA queue with a vmcnt(0) of its own), BEHIND the
-        // DMA pieces of tile t + 1:    [8 DMA pieces], res 0, res 1, res 2, res 3.
-        // The four residual loads are of one kind and retire in order among themselves; nothing is assumed about LDS-DMA or
-        // stores relative to them (an earlier version requested res 0 / 1 in front of the DMA and counted the DMA pieces as
-        // "younger loads": bit-reproducibility of a B = 32, T = 100 restoration broke - a DMA piece can retire before an
-        // older plain load).  Pair pp waits for "at most 3 - pp operations outstanding": were res pp still in flight, the
-        // 3 - pp residuals behind it would be too.  Pair 0's epilogue comes ~3 k cycles after the DMA issue, so the count
-        // rarely holds it up; pair 3's vmcnt(0) also covers this wave's DMA pieces: the barrier at the top of the next tile
-        // needs no wait in front of it.
+        // Store item pp of this lane: pixel 64 pp + lane, features 8 g .. 8 g + 7.  Its residual (16 bytes) is requested one pair
+        // AHEAD by LDS-DMA into this wave's staging slot, in front of that pair's share of the DMA pieces of tile t + 1
+        // (do_pair).  History: plain asm loads with counted waits that took younger DMA pieces for "still in flight" broke
+        // bit-reproducibility of a B = 32, T = 100 restoration - an LDS-DMA can retire before an older plain load; plain
+        // loads with vmcnt(0) drained the queue every pair.
         int nb = b, nty = ty, ntx = tx + 1;                          // tile t + 1
         if (ntx == p.tiles_x) { ntx = 0; if (++nty == p.tiles_y) { nty = 0; ++nb; } }
-        if (!last) issue_tile(nb, nty, ntx, buf ^ 1);
-        u32x4_t rv0 = asm_load16(resb, rel2);
-        u32x4_t rv1 = asm_load16(resb + pp_step, rel2);
-        u32x4_t rv2 = asm_load16(resb + 2 * pp_step, rel2);
-        u32x4_t rv3 = asm_load16(resb + 3 * pp_step, rel2);
-        WS_STAMP();                                                 // residuals requested, next tile's DMA issued
+        const bf16_t* hbn = halo_base(nb, nty, ntx);
+        const float* gbn = guide_base(nb, nty, ntx);
+        const unsigned char* resn = res_base(nb, nty, ntx);
+        WS_STAMP();                                                 // (nothing is issued here any more)
 
 #pragma unroll
         for (int j = 0; j < NK; ++j) bj[j] = buf ? bj[j] + AkWs::HALO : bj[j] - AkWs::HALO;     // in place: NK registers, not 2 NK
         const unsigned attq = att_lane + buf * AkWs::ATT;
 
         float s1 = 0.f, s2 = 0.f;
-        auto do_pair = [&](auto ppc, u32x4_t& rvp, auto wait_res) {
+        // This pair's share of the DMA pieces of tile t + 1.  (Issuing them at a different point of the pair per wave class -
+        // before / inside / behind the K loop / here - so that the eight waves do not ask at the same moment was measured:
+        // 188 -> 193 us and 108 -> 115 us.  The wait is not a queue of simultaneous requests.)
+        auto issue_dma = [&](auto ppc) {
+            constexpr int PP = decltype(ppc)::value;
+            if constexpr (PP == 0) { issue_piece(std::integral_constant<int, 0>{}, hbn, gbn, buf ^ 1); issue_piece(std::integral_constant<int, 1>{}, hbn, gbn, buf ^ 1); issue_piece(std::integral_constant<int, 2>{}, hbn, gbn, buf ^ 1); }
+            if constexpr (PP == 1) { issue_piece(std::integral_constant<int, 3>{}, hbn, gbn, buf ^ 1); issue_piece(std::integral_constant<int, 4>{}, hbn, gbn, buf ^ 1); issue_piece(std::integral_constant<int, 5>{}, hbn, gbn, buf ^ 1); }
+            if constexpr (PP == 2) { issue_piece(std::integral_constant<int, 6>{}, hbn, gbn, buf ^ 1); issue_piece(std::integral_constant<int, 7>{}, hbn, gbn, buf ^ 1); }
+        };
+        auto do_pair = [&](auto ppc) {
             constexpr int PP = decltype(ppc)::value;
             const int pp = PP;
             // ---- accumulators start at the fold constants of the pixel's border class --------------------------------
@@ -359,7 +396,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
                 }
             WS_STAMP();                                             // modulation sum + exchange done
             // ---- swish + residual + statistics + 16-byte store -----------------------------------------------------------
-            wait_res();
+            // (c) this lane's pixel: residual chunk from the staging slot, swish + residual, statistics, result back in place
+            const unsigned stg = stg_lane + (PP & 1) * 8192;
+            const u32x4_t rvp = *reinterpret_cast<const u32x4_t*>(smem + stg);
             float vv[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -368,14 +407,39 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s1 += vv[i]; s2 += vv[i] * vv[i]; }
-            *reinterpret_cast<uint4*>(outb + pp * pp_step + rel2) = pack8_bf16(vv);
+            {
+                const uint4 pk = pack8_bf16(vv);
+                *reinterpret_cast<u32x4_t*>(smem + stg) = (u32x4_t){pk.x, pk.y, pk.z, pk.w};
+            }
+            WS_STAMP2();
+            // S(q): the residual lines of pair q + 1 (this wave's DMA, issued behind S(q - 1)) have landed.  In flight, oldest
+            // first: the store behind S(q - 1), that residual DMA, the n pieces issued behind it (3 | 3, none in the last tile
+            // of the range).  LDS-DMAs retire in order, the store at any time: "at most n outstanding" = at least two retired
+            // = the residual among them.  Pairs 0 and 3 have nothing (that may stay) in flight: pair 3 is the tile barrier.
+            if constexpr (PP == 0 || PP == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            WS_STAMP2();
+            // (e) whole lines out: pixels 8 w .. 8 w + 7 of the pair
+            {
+                const u32x4_t ln = *reinterpret_cast<const u32x4_t*>(smem + line_lane + (PP & 1) * 8192);
+                *reinterpret_cast<u32x4_t*>(outb + pp * pp_step + rel3) = ln;
+            }
+            asm volatile("" ::: "memory");
+            // residual lines of pair q + 2 into the rows just read (nobody else touches them before S(q + 1)), then this
+            // pair's share of the DMA pieces of tile t + 1
+            if constexpr (PP < 2) issue_res(resb + (PP + 2) * pp_step, PP & 1);
+            else if (!last) issue_res(resn + (PP - 2) * pp_step, PP & 1);
+            if (!last) issue_dma(ppc);
+            WS_STAMP2();
             WS_STAMP();                                             // pair stored
             __builtin_amdgcn_sched_barrier(0);                       // pairs are not interleaved by the compiler (register pressure)
         };
-        do_pair(std::integral_constant<int, 0>{}, rv0, [&]() { WS_WAIT_RES(3, rv0); });
-        do_pair(std::integral_constant<int, 1>{}, rv1, [&]() { WS_WAIT_RES(2, rv1); });
-        do_pair(std::integral_constant<int, 2>{}, rv2, [&]() { WS_WAIT_RES(1, rv2); });
-        do_pair(std::integral_constant<int, 3>{}, rv3, [&]() { WS_WAIT_RES(0, rv3); });
+        do_pair(std::integral_constant<int, 0>{});
+        do_pair(std::integral_constant<int, 1>{});
+        do_pair(std::integral_constant<int, 2>{});
+        do_pair(std::integral_constant<int, 3>{});
         S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
         b = nb; ty = nty; tx = ntx;
     }
