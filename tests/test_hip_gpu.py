@@ -126,7 +126,7 @@ def test_akgm_persistent(args):
     assert m["max_abs"] == m2["max_abs"] and m["rel_rms"] == m2["rel_rms"] and m["stats"] == m2["stats"]     # reproducible
 
 
-@pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18)])
+@pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18), (3, 256, 20, 24), (5, 512, 18, 18)])
 @pytest.mark.parametrize("flash", [1, -1], ids=["flash", "engine_choice"])
 def test_attention(shape, flash):
     m = C.attention_case(*shape, flash=flash)

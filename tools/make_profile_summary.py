@@ -29,8 +29,12 @@ def bench_name(k):
         return "akgm_halo"                          # <true> / <false> instantiations share one bench row
     if "akgm_pre_kernel" in k:
         return "akgm_pre"
+    if "akgm_ws_kernel<16>" in k:
+        return "akgm_ws<16>"
     if "akgm_ws_kernel" in k:
-        return "akgm_ws"
+        return "akgm_ws<8>"
+    if "qkv_ws_kernel" in k:
+        return "qkv_ws"
     if "conv_ws128_kernel" in k:
         return "conv_ws<128->64>+res"
     if "conv_ws_kernel" in k:

@@ -22,6 +22,7 @@
 #include "conv_ws.hip.h"
 #include "conv_ws128.hip.h"
 #include "flash_attn.hip.h"
+#include "qkv_ws.hip.h"
 #include "common.h"
 #include "misc.hip.h"
 #include "pack.h"
@@ -99,6 +100,7 @@ struct ConvW {
     bf16_t* A10 = nullptr; float* bias_res = nullptr;   // conv1 + the block's res_conv as a 10th tap (64-row tiles only)
     bf16_t* Aws = nullptr;                               // 3x3 64 -> 64: A fragments of the persistent weight-stationary kernel (conv_ws.hip.h)
     bf16_t* Aws128 = nullptr;                            // 3x3 128 -> 64 + res_conv: A fragments of conv_ws128_kernel (72 steps, then the res_conv's 8)
+    bf16_t* Aqkv = nullptr;                              // 1x1 C -> 3C of SelfAttention: fragments of qkv_ws_kernel (qkv_ws.hip.h)
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -118,6 +120,7 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     if (W.fold) { W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg); }
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
     if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
+    if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
 }
 static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
@@ -181,6 +184,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel<8>, AkWs::LDS); set_lds_attr(akgm_ws_kernel<16>, AkWs::LDS);
+    set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
     set_lds_attr(final_conv_kernel, 160 * 1024);
@@ -744,6 +748,34 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
     const int C = x.C, N = x.H * x.W, B = x.B, Npad = ((N + 63) / 64) * 64;
     require(C % 128 == 0, "attention: channels must be a multiple of 128");
     require((size_t)N <= (size_t)a.N && C == a.C && B <= a.B, "attention buffers too small");
+    // 1 + 2. q, k -> qkv, v' -> V't straight from one persistent weight-stationary GEMM (qkv_ws.hip.h); UCDIR_NO_QKV_WS falls back
+    static const bool use_qkv_ws = !getenv("UCDIR_NO_QKV_WS");
+    const bool qws = use_qkv_ws && wqkv.Aqkv && !a.half && (C == 256 || C == 512);
+    if (qws) {
+        QkvP q;
+        q.A = wqkv.Aqkv; q.x = x.p; q.x_bstride = x.bstride();
+        q.H = x.H; q.W = x.W; q.Wp = x.W + 2; q.N = N; q.nbatch = B; q.tps = (N + 127) / 128; q.rowtiles = 3 * C / 256;
+        q.stats = x.stats; q.inv_count = 1.0 / ((double)C * N);
+        q.Tb = wqkv.Tb; q.Tg = wqkv.Tg;
+        q.qkv = a.qkv; q.qkv_bstride = (long long)N * 3 * C; q.ld = 3 * C;
+        q.vt = a.Vt; q.vt_bstride = (long long)C * Npad; q.Npad = Npad;
+        const int units = q.rowtiles * B * q.tps, ncu = num_cus();
+        const int grid = units < ncu ? units : ncu;
+        auto launch = [&]() {
+            if (C == 512) hipLaunchKernelGGL(qkv_ws_kernel<512>, dim3(grid), dim3(HC_THREADS), QkvWs::LDS, st, q);
+            else hipLaunchKernelGGL(qkv_ws_kernel<256>, dim3(grid), dim3(HC_THREADS), QkvWs::LDS, st, q);
+        };
+        if (g_prof.on) {
+            ProfEntry e; e.key = 105; e.flops = 2.0 * 3 * C * (double)C * N * B; e.bytes = ((double)N * C * 2 + (double)N * 3 * C * 2) * B + 3.0 * C * C * 2;
+            e.dH = x.H; e.dW = x.W; e.dCin = C; e.dCout = 3 * C;
+            e.e0 = g_prof.get(); e.e1 = g_prof.get();
+            HIPC(hipEventRecord(e.e0, st));
+            launch();
+            HIPC(hipEventRecord(e.e1, st));
+            g_prof.entries.push_back(e);
+        } else launch();
+        HIPC(hipGetLastError());
+    } else {
     // 1. q,k,v = conv1x1(GN(x))   (GroupNorm folded; output compact [B][N][3C])
     {
         GemmP p; zero_gemm(p);
@@ -762,6 +794,7 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
     // 2. V^T [B][C][Npad]
     hipLaunchKernelGGL(transpose_v_kernel, dim3((Npad + 31) / 32, C / 32, B), dim3(256), 0, st,
                        a.qkv, N, 3 * C, 2 * C, C, Npad, a.Vt);
+    }
     if (a.flash) {
         // 3. one kernel: QK^T -> online softmax -> P V' + bias + x, GroupNorm statistics of y (flash_attn.hip.h)
         FlashP f;

@@ -206,6 +206,26 @@ static inline std::vector<bf16_t> pack_akgm_pre(const float* wsp, const float* g
     return img;
 }
 
+// A / B fragments of qkv_ws_kernel (qkv_ws.hip.h): [row tile rt of 256][wave 8][k step j = C/16][lane half hh][32 rows][8] bf16;
+// lane (hh, rho) of wave w holds W[R][16 j + 8 hh .. + 7].  q / k row tiles (rows < 2C): R = 256 rt + 32 w + 16 ((rho >> 2) & 1) +
+// 4 (rho >> 3) + (rho & 3) - the MFMA's output rows 8 a + 4 hh + i of a lane are then 16 consecutive features; v' row tiles: R = 256 rt
+// + 32 w + rho (the registers are the B operand there, a lane = one feature).  P: pack_conv image of the 1x1 conv, [rows_pad][Kpad].
+static inline std::vector<bf16_t> pack_qkv_ws(const PackedConv& P, int C) {
+    const int RT = 3 * C / 256, NKS = C / 16;
+    std::vector<bf16_t> img((size_t)RT * 8 * NKS * 2 * 32 * 8, 0);
+    for (int rt = 0; rt < RT; ++rt)
+        for (int w = 0; w < 8; ++w)
+            for (int rho = 0; rho < 32; ++rho) {
+                const bool v = rt * 256 >= 2 * C;
+                const int R = 256 * rt + 32 * w + (v ? rho : 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3));
+                for (int j = 0; j < NKS; ++j)
+                    for (int hh = 0; hh < 2; ++hh)
+                        for (int e = 0; e < 8; ++e)
+                            img[(((((size_t)rt * 8 + w) * NKS + j) * 2 + hh) * 32 + rho) * 8 + e] = P.A[(size_t)R * P.Kpad + 16 * j + 8 * hh + e];
+            }
+    return img;
+}
+
 // A fragments of stem_mfma_kernel (misc.hip.h): [C0/64 blocks][tm 2][k16 step j 5][lane 64][8] bf16; lane = (k half
 // hh = lane >> 5, row = lane & 31): tap 2j + hh, channel slot e (e >= cin zero).  The tenth tap slot (j = 4, hh = 1)
 // carries the BIAS as bf16 hi + lo parts in slots 0 and 1 (the kernel feeds it the constant (1, 1, 0, ...)), so the
