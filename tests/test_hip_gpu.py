@@ -109,9 +109,14 @@ def test_akgm(Cc):
     (3, 128, 32, 48, 4096),  # 16 channels per group: one 64-channel plane per workgroup, one tile per workgroup pair
     (3, 128, 64, 80, 14),    # ... ranges of 8-9 tiles that cross sample boundaries (7 workgroup pairs)
     (8, 128, 144, 144, 0),   # ... the network's 144^2 level on one workgroup per CU
-], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0", "cg16_small", "cg16_ranges", "cg16_level1"])
+    (3, 256, 32, 48, 4096),  # 32 channels per group (akgm_ws32_kernel): one group per workgroup, 32 x 8 tiles, one tile per workgroup
+    (2, 256, 48, 40, 16),    # ... 24 x 8 tiles, ranges of 10 tiles that cross the sample boundary (two workgroups per group)
+    (5, 256, 72, 72, 0),     # ... the network's 72^2 level on one workgroup per CU
+], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0", "cg16_small", "cg16_ranges", "cg16_level1",
+        "cg32_small", "cg32_ranges", "cg32_level2"])
 def test_akgm_persistent(args):
-    """akgm_ws_kernel (8 | 16 channels per group, persistent, weight-stationary): tile ranges, sample crossings, border classes."""
+    """akgm_ws_kernel / akgm_ws32_kernel (8 | 16 | 32 channels per group, persistent, weight-stationary): tile ranges, sample
+    crossings, border classes."""
     B, Cc, H, W, grid = args
     L = C.ulib.load()
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))

@@ -226,6 +226,28 @@ static inline std::vector<bf16_t> pack_qkv_ws(const PackedConv& P, int C) {
     return img;
 }
 
+// A fragments of akgm_ws32_kernel (akgm_ws32.hip.h), 32 channels per group: [group 8][wave 8][k step j 18][lane half hh][32 rows][8] bf16.
+// Wave w of group g owns features c = 32 g + 4 w + c4; MFMA row rho <-> (c4 = 2 ((rho >> 2) & 1) + (rho >> 4), sample s = 4 ((rho >> 3) & 1)
+// + (rho & 3)): a lane's 16 accumulators (rows 8 a + 4 hh + i) are then the 8 samples of features 2 hh and 2 hh + 1.  k step j = tap j / 2,
+// channels 16 (j & 1) + 8 hh .. + 7.  wsp: [8C][cg][3][3] (row o = 8 c + s), gamma: [C].
+static inline std::vector<bf16_t> pack_akgm_ws32(const float* wsp, const float* gamma, int C) {
+    const int cg = C / 8;
+    std::vector<bf16_t> img((size_t)8 * 8 * 18 * 2 * 32 * 8, 0);
+    for (int g = 0; g < 8; ++g)
+        for (int w = 0; w < 8; ++w)
+            for (int rho = 0; rho < 32; ++rho) {
+                const int c4 = 2 * ((rho >> 2) & 1) + (rho >> 4), sm = 4 * ((rho >> 3) & 1) + (rho & 3);
+                const int c = 32 * g + 4 * w + c4, o = 8 * c + sm;
+                for (int j = 0; j < 18; ++j)
+                    for (int hk = 0; hk < 2; ++hk)
+                        for (int e = 0; e < 8; ++e) {
+                            const int tap = j >> 1, ci = 16 * (j & 1) + 8 * hk + e;
+                            img[(((((size_t)g * 8 + w) * 18 + j) * 2 + hk) * 32 + rho) * 8 + e] = f2bf(wsp[((size_t)o * cg + ci) * 9 + tap] * gamma[g * cg + ci]);
+                        }
+            }
+    return img;
+}
+
 // A fragments of stem_mfma_kernel (misc.hip.h): [C0/64 blocks][tm 2][k16 step j 5][lane 64][8] bf16; lane = (k half
 // hh = lane >> 5, row = lane & 31): tap 2j + hh, channel slot e (e >= cin zero).  The tenth tap slot (j = 4, hh = 1)
 // carries the BIAS as bf16 hi + lo parts in slots 0 and 1 (the kernel feeds it the constant (1, 1, 0, ...)), so the
