@@ -30,8 +30,14 @@ struct AkWs32 {
     static constexpr int LDS = OFF_TCS + 9 * 1024;                // 110,592
 };
 
+// CG = 32: as described above.  CG = 16 | 8 (C = 128 | 64): the workgroup owns a BLOCK of 32 features = 2 | 4 groups (the same 64
+// bytes of a pixel), wave w the features 4 w .. 4 w + 3 of the block (group w / 4 | w / 2 of it): K = 9 x 16 = 9 steps of one tap |
+// 9 x 8 (+ one zero tap) = 5 steps of two taps; everything else - tiles, staging, epilogue - is shared.
+template <int CG>
 __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p) {
-    constexpr int NK = 18;                                         // k steps: tap j / 2, channels 16 (j & 1) .. + 15
+    constexpr int NK = (CG == 32) ? 18 : ((CG == 16) ? 9 : 5);     // k steps (CG 32: tap j / 2, channels 16 (j & 1) .. + 15)
+    constexpr int CPX = 8 * CG;                                    // channels per pixel
+    constexpr int NB = CPX / 32;                                   // 32-feature blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,8 +48,8 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    // workgroup -> (group, range of tiles): workgroups lid, lid + 8, ... share group lid & 7
-    const int g = lid & 7, slot = lid >> 3, nwg = ((int)gridDim.x - g + 7) >> 3;
+    // workgroup -> (block, range of tiles): workgroups lid, lid + NB, ... share block lid % NB
+    const int g = lid % NB, slot = lid / NB, nwg = ((int)gridDim.x - g + NB - 1) / NB;
     const int TH = p.th, NPT = TH >> 2;                            // tile rows, pixel tiles per tile
     const int tps = p.tiles_x * p.tiles_y, T = p.nbatch * tps;
     const int t_beg = (int)((long long)slot * T / nwg), t_end = (int)((long long)(slot + 1) * T / nwg);
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
     for (int i = 0; i < 4; ++i) {
         const int k = i * 8 + wave, hp = 16 * k + (lane >> 2);
         const int r = hp / AkWs32::PITCH, c = hp - r * AkWs32::PITCH;
-        hrel[i] = (k < npiece && c < 10 && r < TH + 2) ? (r * p.Wp + c) * 256 + 32 * g + (((lane & 3) ^ fsw(r, c)) << 3) : -1;
+        hrel[i] = (k < npiece && c < 10 && r < TH + 2) ? (r * p.Wp + c) * CPX + 32 * g + (((lane & 3) ^ fsw(r, c)) << 3) : -1;
     }
     // guide piece k (4 tile rows = 32 pixels x 32 B): wave w stages piece w (k < NPT)
     const int grel = ((4 * wave + (lane >> 4)) * p.W + ((lane >> 1) & 7)) * 8 + (lane & 1) * 4;
@@ -77,21 +83,27 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int k = i * 8 + wave, px = 16 * k + (lane >> 2);
-        rrel[i] = (((px >> 3) + 1) * p.Wp + (px & 7) + 1) * 256 + 32 * g + (((lane & 3) ^ ((px >> 2) & 3)) << 3);
+        rrel[i] = (((px >> 3) + 1) * p.Wp + (px & 7) + 1) * CPX + 32 * g + (((lane & 3) ^ ((px >> 2) & 3)) << 3);
     }
     // line mover: thread -> (pixel 128 i + tid / 4, physical chunk tid & 3), i = 0, 1
     int srel[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int px = 128 * i + (tid >> 2);
-        srel[i] = (((px >> 3) + 1) * p.Wp + (px & 7) + 1) * 256 + 32 * g + (((tid & 3) ^ ((px >> 2) & 3)) << 3);
+        srel[i] = (((px >> 3) + 1) * p.Wp + (px & 7) + 1) * CPX + 32 * g + (((tid & 3) ^ ((px >> 2) & 3)) << 3);
     }
-    // B fragment of tap t, channel half 0, pixel tile 0, buffer 0: LDS byte address (half 1: ^ 32; pixel tile q: + q QSTEP)
-    unsigned bt[9];
+    // B fragment of k step j, pixel tile 0, buffer 0: LDS byte address (pixel tile q: + q QSTEP).
+    // CG 32: bt[t] = tap t, channel half 0; step j = tap j / 2, half j & 1: bt[j / 2] ^ 32 [j & 1]
+    // CG 16: bt[j] = tap j, the group's chunk pair 2 (w / 4) + lane half
+    // CG 8 : bt[j] = tap 2 j (lanes 0-31) | 2 j + 1 (lanes 32-63; tap 9 has zero weights: reads tap 8), the group's chunk w / 2
+    constexpr int NBT = (CG == 8) ? 5 : 9;
+    unsigned bt[NBT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int r = prow + t / 3, c = pcol + t % 3;
-        bt[t] = (r * AkWs32::PITCH + c) * 64 + ((hh ^ fsw(r, c)) << 4);
+    for (int t = 0; t < NBT; ++t) {
+        const int tap = (CG == 8) ? ((2 * t + hh > 8) ? 8 : 2 * t + hh) : t;
+        const int chunk = (CG == 32) ? hh : ((CG == 16) ? 2 * (wave >> 2) + hh : (wave >> 1));
+        const int r = prow + tap / 3, c = pcol + tap % 3;
+        bt[t] = (r * AkWs32::PITCH + c) * 64 + ((chunk ^ fsw(r, c)) << 4);
     }
     const unsigned tc_lane = AkWs32::OFF_TCS + 4 * 8 * (4 * wave + 2 * hh);            // + 1024 cls: this lane's 16 table entries (2 features x 8 samples)
     const unsigned att_lane = AkWs32::OFF_ATT + l31 * 32;                                // + 1024 q: this lane's pixel of pixel tile q
@@ -105,14 +117,14 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
         ty = r / p.tiles_x; tx = r - ty * p.tiles_x;
     }
     auto issue_tile = [&](int nb, int nty, int ntx, int buf) {
-        const bf16_t* hb = p.h + (long long)nb * p.h_bstride + (long long)(nty * TH * p.Wp + ntx * 8) * 256;
+        const bf16_t* hb = p.h + (long long)nb * p.h_bstride + (long long)(nty * TH * p.Wp + ntx * 8) * CPX;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (hrel[i] >= 0) stage16(hb + hrel[i], smem + buf * AkWs32::HALO + (i * 8 + wave) * 1024, lane);
         if (wave < NPT)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.G + (long long)nb * p.g_bstride + (long long)(nty * TH * p.W + ntx * 8) * 8 + grel),
                                              (LDS_AS void*)(smem + AkWs32::OFF_ATT + buf * AkWs32::ATT + wave * 1024), 16, 0, 0);
-        const bf16_t* rb = p.res + (long long)nb * p.res_bstride + (long long)(nty * TH * p.Wp + ntx * 8) * 256;
+        const bf16_t* rb = p.res + (long long)nb * p.res_bstride + (long long)(nty * TH * p.Wp + ntx * 8) * CPX;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (i * 8 + wave < 2 * NPT) stage16(rb + rrel[i], smem + AkWs32::OFF_STAGE + buf * AkWs32::STAGE + (i * 8 + wave) * 1024, lane);
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
             for (int i = 0; i < 2; ++i) {
                 const int pc = i * 8 + wave;
                 if (pc < 9)
-                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + pc) * 2048 + 256 * g + lane * 4),
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + pc) * (8 * CPX) + 256 * g + lane * 4),
                                                      (LDS_AS void*)(smem + AkWs32::OFF_TCS + pc * 1024), 16, 0, 0);
             }
             rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fold constants; nothing of the compiler's own is queued behind this
             auto frag = [&](auto jc, bf16x8_t (&dst)[2]) {
                 constexpr int j = decltype(jc)::value;
-                const unsigned a0 = (bt[j >> 1] ^ ((j & 1) << 5)) + qoff;
+                const unsigned a0 = ((CG == 32) ? (bt[j >> 1] ^ ((j & 1) << 5)) : bt[j < NBT ? j : 0]) + qoff;
                 lds_read16_asm<0>(dst[0], a0);
                 lds_read16_asm<AkWs32::QSTEP>(dst[1], a0);
             };
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
         }
         S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
         have_prev = true;
-        prev_out = ((long long)b * p.out_bstride + (long long)(ty * TH * p.Wp + tx * 8) * 256) * 2;
+        prev_out = ((long long)b * p.out_bstride + (long long)(ty * TH * p.Wp + tx * 8) * CPX) * 2;
         b = nb; ty = nty; tx = ntx;
     }
     if (p.stats_out) {

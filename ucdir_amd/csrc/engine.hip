@@ -106,7 +106,7 @@ struct ConvW {
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
     bf16_t* Apre = nullptr;        // cg 8 / 16: LDS image for akgm_pre.hip.h
-    bf16_t* Aws32 = nullptr;       // cg 32: A fragments of akgm_ws32_kernel
+    bf16_t* Aws32 = nullptr;       // cg 8 / 16 / 32: A fragments of akgm_ws32_kernel<cg>
     int C = 0, cg = 0, Kpad = 0;
 };
 
@@ -135,7 +135,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
     if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
-    if (P.cg == 32) W.Aws32 = pool.upload(pack_akgm_ws32(wsp, gamma, C));
+    if (P.cg == 32 || P.cg == 16 || P.cg == 8) W.Aws32 = pool.upload(pack_akgm_ws32(wsp, gamma, C));
     return W;
 }
 
@@ -187,7 +187,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_halo_stage_kernel, AH_LDS); set_lds_attr(akgm_halo_kernel<true>, AH_LDS);
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel<8>, AkWs::LDS); set_lds_attr(akgm_ws_kernel<16>, AkWs::LDS);
-    set_lds_attr(akgm_ws32_kernel, AkWs32::LDS);
+    set_lds_attr(akgm_ws32_kernel<32>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<16>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<8>, AkWs32::LDS);
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
@@ -625,11 +625,21 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     static const bool use_ws32 = !getenv("UCDIR_NO_WS32");
     int th32 = 0;
     for (int cand : {32, 24, 16, 8}) if (y.H % cand == 0) { th32 = cand; break; }
-    const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && w.cg == 32 && w.C == 256 && th32 > 0 && y.W % 8 == 0 &&
-                      (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * 8 >= 4LL * num_cus());
+    // (UCDIR_WSB=1: the block kernel also at 8 / 16 channels per group instead of akgm_ws_kernel - A/B switch)
+    static const bool wsb_all = getenv("UCDIR_WSB") != nullptr;
+    const int nb32 = w.C / 32;
+    const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && (w.cg == 32 || (wsb_all && (w.cg == 16 || w.cg == 8))) && w.C == 8 * w.cg && th32 > 0 && y.W % 8 == 0 &&
+                      (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * nb32 >= 4LL * num_cus());
     if (ws32) { p.A = w.Aws32; p.th = th32; p.tw = 8; p.tiles_x = y.W / 8; p.tiles_y = y.H / th32; }
     auto launch = [&]() {
-        if (ws) {
+        if (ws32) {
+            const int ntiles = y.B * p.tiles_x * p.tiles_y;
+            int ncu = num_cus() / nb32 * nb32; if (ncu < nb32) ncu = nb32;
+            const int grid = nb32 * ntiles < ncu ? nb32 * ntiles : ncu;      // one workgroup per 32-feature block per tile range
+            if (w.cg == 32) hipLaunchKernelGGL(akgm_ws32_kernel<32>, dim3(grid), dim3(HC_THREADS), AkWs32::LDS, st, p);
+            else if (w.cg == 16) hipLaunchKernelGGL(akgm_ws32_kernel<16>, dim3(grid), dim3(HC_THREADS), AkWs32::LDS, st, p);
+            else hipLaunchKernelGGL(akgm_ws32_kernel<8>, dim3(grid), dim3(HC_THREADS), AkWs32::LDS, st, p);
+        } else if (ws) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus();
             const int grid = ntiles < ncu ? ntiles : ncu;
             hipLaunchKernelGGL(akgm_ws_kernel<8>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
@@ -637,11 +647,6 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
             const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus() & ~1;
             const int grid = 2 * ntiles < ncu ? 2 * ntiles : ncu;            // workgroup pairs: (tile range, channel plane)
             hipLaunchKernelGGL(akgm_ws_kernel<16>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
-        } else if (ws32) {
-            const int ntiles = y.B * p.tiles_x * p.tiles_y;
-            int ncu = num_cus() & ~7; if (ncu < 8) ncu = 8;
-            const int grid = 8 * ntiles < ncu ? 8 * ntiles : ncu;            // eight workgroups (one per group) per tile range
-            hipLaunchKernelGGL(akgm_ws32_kernel, dim3(grid), dim3(HC_THREADS), AkWs32::LDS, st, p);
         } else if (pre) {
             hipLaunchKernelGGL(akgm_pre_kernel<8>, dim3(nblk), dim3(HC_THREADS), AkPre<8>::LDS, st, p);
         } else if (att_lds) hipLaunchKernelGGL(akgm_halo_kernel<true>, dim3(nblk), dim3(HC_THREADS), AH_LDS, st, p);
@@ -664,7 +669,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = ws ? 113 : (ws16 ? 114 : (ws32 ? 115 : (pre ? 112 : 111))); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        ProfEntry e; e.key = ws32 ? 115 : (ws ? 113 : (ws16 ? 114 : (pre ? 112 : 111))); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
         e.dH = y.H; e.dW = y.W; e.dCin = w.C; e.dCout = w.C;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();

@@ -226,23 +226,26 @@ static inline std::vector<bf16_t> pack_qkv_ws(const PackedConv& P, int C) {
     return img;
 }
 
-// A fragments of akgm_ws32_kernel (akgm_ws32.hip.h), 32 channels per group: [group 8][wave 8][k step j 18][lane half hh][32 rows][8] bf16.
-// Wave w of group g owns features c = 32 g + 4 w + c4; MFMA row rho <-> (c4 = 2 ((rho >> 2) & 1) + (rho >> 4), sample s = 4 ((rho >> 3) & 1)
-// + (rho & 3)): a lane's 16 accumulators (rows 8 a + 4 hh + i) are then the 8 samples of features 2 hh and 2 hh + 1.  k step j = tap j / 2,
-// channels 16 (j & 1) + 8 hh .. + 7.  wsp: [8C][cg][3][3] (row o = 8 c + s), gamma: [C].
+// A fragments of akgm_ws32_kernel<CG> (akgm_ws32.hip.h): [32-feature block C/32][wave 8][k step j NK][lane half hh][32 rows][8] bf16.
+// Wave w of block blk owns features c = 32 blk + 4 w + c4; MFMA row rho <-> (c4 = 2 ((rho >> 2) & 1) + (rho >> 4), sample s = 4 ((rho >> 3) & 1)
+// + (rho & 3)): a lane's 16 accumulators (rows 8 a + 4 hh + i) are then the 8 samples of features 2 hh and 2 hh + 1.  k step j, lane half hk:
+// cg 32: tap j / 2, channels 16 (j & 1) + 8 hk ..;  cg 16: tap j, channels 8 hk ..;  cg 8: tap 2 j + hk (tap 9 = zero), channels 0 .. 7.
+// wsp: [8C][cg][3][3] (row o = 8 c + s), gamma: [C].
 static inline std::vector<bf16_t> pack_akgm_ws32(const float* wsp, const float* gamma, int C) {
-    const int cg = C / 8;
-    std::vector<bf16_t> img((size_t)8 * 8 * 18 * 2 * 32 * 8, 0);
-    for (int g = 0; g < 8; ++g)
+    const int cg = C / 8, nk = (cg == 32) ? 18 : ((cg == 16) ? 9 : 5), nb = C / 32;
+    std::vector<bf16_t> img((size_t)nb * 8 * nk * 2 * 32 * 8, 0);
+    for (int blk = 0; blk < nb; ++blk)
         for (int w = 0; w < 8; ++w)
             for (int rho = 0; rho < 32; ++rho) {
                 const int c4 = 2 * ((rho >> 2) & 1) + (rho >> 4), sm = 4 * ((rho >> 3) & 1) + (rho & 3);
-                const int c = 32 * g + 4 * w + c4, o = 8 * c + sm;
-                for (int j = 0; j < 18; ++j)
+                const int c = 32 * blk + 4 * w + c4, o = 8 * c + sm, g = c / cg;
+                for (int j = 0; j < nk; ++j)
                     for (int hk = 0; hk < 2; ++hk)
                         for (int e = 0; e < 8; ++e) {
-                            const int tap = j >> 1, ci = 16 * (j & 1) + 8 * hk + e;
-                            img[(((((size_t)g * 8 + w) * 18 + j) * 2 + hk) * 32 + rho) * 8 + e] = f2bf(wsp[((size_t)o * cg + ci) * 9 + tap] * gamma[g * cg + ci]);
+                            const int tap = (cg == 32) ? (j >> 1) : ((cg == 16) ? j : 2 * j + hk);
+                            const int ci = (cg == 32) ? 16 * (j & 1) + 8 * hk + e : ((cg == 16) ? 8 * hk + e : e);
+                            if (tap > 8) continue;
+                            img[(((((size_t)blk * 8 + w) * nk + j) * 2 + hk) * 32 + rho) * 8 + e] = f2bf(wsp[((size_t)o * cg + ci) * 9 + tap] * gamma[g * cg + ci]);
                         }
             }
     return img;
