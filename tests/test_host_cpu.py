@@ -407,3 +407,11 @@ def test_in_place_weight_updates_change_the_signature():
         assert s2 != s1
         torch.nn.init.normal_(list(net.parameters())[0])
         assert net._weights_signature() != s2
+
+
+def test_graft_entry_build():
+    """The driver's "does it build" entry point runs here without a GPU (and does not carry a stale ABI number)."""
+    import importlib
+    import __graft_entry__ as g
+    importlib.reload(g)
+    g.build()
