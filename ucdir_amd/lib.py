@@ -80,6 +80,11 @@ def load():
         raise UcdirError(
             f"{LIB_PATH} is missing: build it with `python -m ucdir_amd.build` (hipcc, gfx950). "
             "ucdir_amd has no CPU / PyTorch fallback for the denoiser.")
+    # The library shares device memory and streams with PyTorch, so both must sit on ONE HIP runtime: import torch first - its
+    # bundled libamdhip64 is then the one this library's dependency resolves to.  (Loaded the other way round the process holds
+    # two runtimes and the second one to initialise sees no device: `python __graft_entry__.py smoke` failed with "no HIP
+    # device available" behind build(), which loads the library before anything imported torch.)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
