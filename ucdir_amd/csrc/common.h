@@ -171,5 +171,9 @@ struct GemmP {
     // (weights alt_A [rows][alt_a_ld], bias2, output out2): dispatched last, they fill the CUs the 3x3 conv's last partial
     // round of workgroups leaves idle instead of waiting for it in a launch of their own
     int alt_blocks; const bf16_t* alt_A; int alt_a_ld;
+    // conv3x3_halo: the same weights pre-tiled as the kernel's LDS stage images, [row tile][32-channel chunk][K step][16 KB]
+    // (pack_conv_tiled): every LDS-DMA piece of a weight stage is then 1 KB of CONTIGUOUS memory (eight full lines) instead of
+    // sixteen 64-byte half lines.  nullptr: stage from A.
+    const bf16_t* A_tiled;
     unsigned long long* dbg;                // UCDIR_TIMING builds: s_memtime stamps of one workgroup
 };

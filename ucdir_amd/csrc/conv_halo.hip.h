@@ -213,8 +213,16 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         adst[j] = atap[j] * (TM * 64) + (k % (TM / 16)) * 1024;
     }
     const bf16_t* Abase = alt ? p.alt_A : p.A + (long long)par * p.a_gstride;
+    const bool a_tiled = p.A_tiled != nullptr && !alt && !p.up_phase && !res_fused;
+    const bf16_t* Atl = p.A_tiled + ((long long)rowtile * nchunks_all * nsteps_c) * (ASTAGE / 2) + (2 * wave) * 512 + lane * 8;
     auto issue_A = [&](int c, int u, int slot) {      // taps TPS*u .. TPS*u+TPS-1 (tail taps re-stage the last valid one)
         unsigned char* ab = aring + slot * ASTAGE;
+        if (a_tiled) {                                 // pre-tiled image: this wave's two pieces are 2 KB of contiguous memory
+            const bf16_t* src = Atl + (long long)(c * nsteps_c + u) * (ASTAGE / 2);
+            stage16(src, ab + (2 * wave) * 1024, lane);
+            stage16(src + 512, ab + (2 * wave + 1) * 1024, lane);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int t = TPS * u + atap[j];

@@ -102,6 +102,7 @@ struct ConvW {
     bf16_t* Aws = nullptr;                               // 3x3 64 -> 64: A fragments of the persistent weight-stationary kernel (conv_ws.hip.h)
     bf16_t* Aws128 = nullptr;                            // 3x3 128 -> 64 + res_conv: A fragments of conv_ws128_kernel (72 steps, then the res_conv's 8)
     bf16_t* Aqkv = nullptr;                              // 1x1 C -> 3C of SelfAttention: fragments of qkv_ws_kernel (qkv_ws.hip.h)
+    bf16_t* Atile = nullptr;                             // 3x3: the weight stages of conv3x3_halo_kernel<TM> as contiguous 16 KB blocks (pack_conv_tiled)
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -122,6 +123,7 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     if (W.fold) { W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg); }
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
     if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
+    if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && P.rows_pad % W.TM == 0) W.Atile = pool.upload(pack_conv_tiled(P, W.TM));
     if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
 }
@@ -463,6 +465,8 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
         did_res = true;
     }
     const bool dual = did_res;                          // conv3x3_halo_kernel<64, true>: second accumulator set
+    static const bool use_atile = !getenv("UCDIR_NO_ATILE");
+    if (use_atile && halo && !upph && !did_res && tm_run == w.TM && w.Atile && w.ntaps == 9) p.A_tiled = w.Atile;
     // 128 -> 64 with the res_conv fused, on 8 x 16 tiles: persistent kernel with one wave per SIMD (conv_ws128.hip.h)
     static const bool use_cws128 = !getenv("UCDIR_NO_CONV_WS128");
     if (use_cws128 && did_res && w.Aws128 && cin == 128 && x0.C == 64 && x1 && x1->C == 64 && !res && !p.out_nchw && y.H % 8 == 0 && y.W % 16 == 0 &&

@@ -226,6 +226,27 @@ static inline std::vector<bf16_t> pack_qkv_ws(const PackedConv& P, int C) {
     return img;
 }
 
+// conv3x3_halo_kernel<TM>'s weight stages as they sit in LDS, [row tile][32-channel chunk c][K step u][piece k 16][lane 64][8] bf16:
+// piece k = rows (k % (TM/16)) * 16 .. + 15 of tap TPS u + k / (TM/16) (tail taps repeat tap 8), lane -> (row lane / 4, physical
+// 16-byte chunk lane & 3 = logical ^ ((row >> 2) & 3)).  A stage is then 16 KB of contiguous memory.  P: pack_conv image [rows_pad][Kpad].
+static inline std::vector<bf16_t> pack_conv_tiled(const PackedConv& P, int TM) {
+    const int TPS = 256 / TM, nsteps = (9 + TPS - 1) / TPS, nch = P.cin / 32, nrt = P.rows_pad / TM, ipt = TM / 16;
+    std::vector<bf16_t> img((size_t)nrt * nch * nsteps * 8192, 0);
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int c = 0; c < nch; ++c)
+            for (int u = 0; u < nsteps; ++u)
+                for (int k = 0; k < 16; ++k)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = (k % ipt) * 16 + (lane >> 2);
+                        int tap = TPS * u + k / ipt; tap = tap < 9 ? tap : 8;
+                        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+                        const bf16_t* src = &P.A[(size_t)(rt * TM + row) * P.Kpad + (size_t)tap * P.cin + c * 32 + lc * 8];
+                        bf16_t* dst = &img[((((size_t)rt * nch + c) * nsteps + u) * 16 + k) * 512 + lane * 8];
+                        for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                    }
+    return img;
+}
+
 // A fragments of akgm_ws32_kernel<CG> (akgm_ws32.hip.h): [32-feature block C/32][wave 8][k step j NK][lane half hh][32 rows][8] bf16.
 // Wave w of block blk owns features c = 32 blk + 4 w + c4; MFMA row rho <-> (c4 = 2 ((rho >> 2) & 1) + (rho >> 4), sample s = 4 ((rho >> 3) & 1)
 // + (rho & 3)): a lane's 16 accumulators (rows 8 a + 4 hh + i) are then the 8 samples of features 2 hh and 2 hh + 1.  k step j, lane half hk:
