@@ -131,6 +131,24 @@ def test_akgm_persistent(args):
     assert m["max_abs"] == m2["max_abs"] and m["rel_rms"] == m2["rel_rms"] and m["stats"] == m2["stats"]     # reproducible
 
 
+@pytest.mark.parametrize("args", [(3, 64, 64, 80, 6), (3, 128, 64, 80, 12), (2, 64, 40, 56, 2)], ids=["cg8", "cg16", "cg8_th8"])
+def test_akgm_block_kernel_at_narrow_groups(args):
+    """akgm_ws32_kernel<8 | 16> (the 32-feature-block kernel templated on the group width; not the default at these widths)."""
+    B, Cc, H, W, grid = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"wsb", 1))
+    C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    try:
+        m = C.akgm_case(B, Cc, H, W, seed=9)
+        m2 = C.akgm_case(B, Cc, H, W, seed=9)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+        C.ulib.check(L.ucdir_debug_flag(b"wsb", -1))
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    assert m["stats_rel"] < 1e-3, m
+    assert m["max_abs"] == m2["max_abs"] and m["rel_rms"] == m2["rel_rms"] and m["stats"] == m2["stats"]
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 12, 10), (1, 512, 36, 36), (1, 512, 18, 18), (3, 256, 20, 24), (5, 512, 18, 18)])
 @pytest.mark.parametrize("flash", [1, -1], ids=["flash", "engine_choice"])
 def test_attention(shape, flash):

@@ -332,6 +332,7 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
 static bool g_use_halo = true;
 
 // compute units of the current device (persistent kernels launch one workgroup per CU)
+static int g_wsb = -1;               // -1: environment (UCDIR_WSB), 0 / 1: ucdir_debug_flag("wsb", v): block AKGM kernel also at 8 / 16 channels per group
 static int g_persist_grid = 0;      // > 0: ucdir_debug_flag("persist_grid", n) forces the grid of the persistent kernels (tests: many tiles per workgroup on small inputs)
 static int num_cus() {
     if (g_persist_grid > 0) return g_persist_grid;
@@ -630,7 +631,8 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     int th32 = 0;
     for (int cand : {32, 24, 16, 8}) if (y.H % cand == 0) { th32 = cand; break; }
     // (UCDIR_WSB=1: the block kernel also at 8 / 16 channels per group instead of akgm_ws_kernel - A/B switch)
-    static const bool wsb_all = getenv("UCDIR_WSB") != nullptr;
+    static const bool wsb_env = getenv("UCDIR_WSB") != nullptr;
+    const bool wsb_all = g_wsb < 0 ? wsb_env : g_wsb != 0;
     const int nb32 = w.C / 32;
     const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && (w.cg == 32 || (wsb_all && (w.cg == 16 || w.cg == 8))) && w.C == 8 * w.cg && th32 > 0 && y.W % 8 == 0 &&
                       (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * nb32 >= 4LL * num_cus());
@@ -1525,6 +1527,7 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     require(name != nullptr, "null argument");
     if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
+    else if (!strcmp(name, "wsb")) g_wsb = value;
     else if (!strcmp(name, "persist_grid")) g_persist_grid = value;   // persistent kernels: workgroups per launch (0 = one per CU)
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END
