@@ -57,6 +57,16 @@ __device__ __forceinline__ void hc_wait_vm(int n) {
     }
 }
 
+// MFMA column (lane & 31) -> pixel slot of a 32-pixel tile.  ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} (+ 32): with this permutation every group reads 16 CONSECUTIVE pixel slots (consecutive halo positions
+// except where a tile row wraps) instead of pieces of two tile rows.  -1..2 % per launch.  (Making the wrap conflict-free too - halo
+// pitch tw + 4 and a swizzle keyed on row * tw + column for widths that are no multiple of 16 - took the conflicts from 25 % to 2-4 %
+// of the LDS cycles at 72^2 / 36^2 and the launches nowhere: 230.6 vs 228.4 us, 264.5 vs 265.1, 18^2 64.5 vs 62.0 - LDS conflicts are not
+// what this kernel waits for; not kept, profiles/EXPERIMENTS.md.)
+__device__ __forceinline__ int hc_px_perm(int l) {
+    return l < 4 ? l : (l < 12 ? l + 12 : (l < 16 ? l - 8 : (l < 20 ? l + 8 : (l < 28 ? l - 12 : l))));
+}
+
 template <int TM, bool DUAL = false>
 __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
     }
 #pragma unroll
     for (int tp = 0; tp < NTP; ++tp) {
-        int slot = wq * TPW + tp * 32 + (lane & 31);
+        int slot = wq * TPW + tp * 32 + hc_px_perm(lane & 31);
         slot = slot < nslots ? slot : nslots - 1;
         const int r = fdiv_small(slot, inv_tw), c = slot - r * tw;
         hp0[tp] = r * hw + c;
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int tp = 0; tp < NTP; ++tp) {
-                const int px = wq * TPW + tp * 32 + (lane & 31);
+                const int px = wq * TPW + tp * 32 + hc_px_perm(lane & 31);
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tp = 0; tp < NTP; ++tp) {
-                    const int px = (wq * TPW) % PXH + tp * 32 + (lane & 31);
+                    const int px = (wq * TPW) % PXH + tp * 32 + hc_px_perm(lane & 31);
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                     for (int tp = 0; tp < NTP; ++tp) {
-                        const int px = (wq * TPW) % PXH + tp * 32 + (lane & 31);
+                        const int px = (wq * TPW) % PXH + tp * 32 + hc_px_perm(lane & 31);
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             const int f = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
