@@ -19,6 +19,7 @@
 // cgemm.hip.h, run in passes of 128 pixels through an fp32 LDS stage.
 #pragma once
 #include "cgemm.hip.h"
+#include "asmops.hip.h"
 
 #define HC_THREADS 512
 #define HC_HALO_PX 324
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void conv3x3_halo_kernel(const GemmP
         if (u == 0 && c + 1 < nchunks) issue_halo(c + 1, (c + 1) & 1);
         HC_STAMP(3);
         const unsigned char* Hb = halo + (c & 1) * HC_HALO_BYTES;
+        // (A hand-pipelined version of this phase - inline-asm fragment reads one sub-step ahead, counted lgkmcnt, a second register
+        // set, 125 VGPRs - was measured: +1..5 % SLOWER at 144^2 / 72^2 / 36^2.  With four waves per SIMD the other waves already
+        // cover a wave's LDS round trips, and the scheduling barriers the counted waits need keep address arithmetic out from under
+        // the MFMAs.)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
