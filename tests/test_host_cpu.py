@@ -345,6 +345,11 @@ def test_patch_cache_is_per_module_and_cleared():
     den = a._patch_cache["den"][1]
     a(x, t, ga)
     assert a._patch_cache["den"][1] is den and a._patch_cache["guide"] is ka        # reused, not re-cut / re-allocated
+    # two forwards of the same shape must not alias (round-3 advice): the result is a fresh tensor, not a view into `den`
+    x2 = torch.randn(1, 6, 150, 210)
+    e1 = a(x, t, ga); e1_copy = e1.clone()
+    e2 = a(x2, t, ga)
+    assert torch.equal(e1, e1_copy) and not torch.equal(e1, e2) and e1.data_ptr() != e2.data_ptr()
     a.clear_patch_cache()
     assert a._patch_cache == {} and "guide" in b._patch_cache
     from ucdir_amd import patch as P

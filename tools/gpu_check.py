@@ -31,6 +31,31 @@ def run(name, fn, *a, **k):
     sys.stdout.flush()
 
 
+def sid_b4():
+    import ctypes
+    import numpy as np
+    from oracle import ucdir_oracle as O
+    from ucdir_amd.weights import synth_inputs
+    net, sd = C.build_net(SID)
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(4, 256, 256, seed=31))
+    lvl = torch.tensor([[0.0029], [0.3], [0.6], [0.95]])
+    x6 = torch.cat([cond, x_t], 1)
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_profile_enable(1))
+    with torch.no_grad():
+        eps = net.denoise_fn(x6.cuda(), lvl.cuda(), guide.cuda()).cpu()
+    C.ulib.check(L.ucdir_profile_enable(0))
+    cap = 64
+    keys, ln = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)()
+    ms, fl, by = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+    nr = ctypes.c_int32(0)
+    C.ulib.check(L.ucdir_profile_read(cap, keys, ln, ms, fl, by, ctypes.byref(nr), C._st()))
+    out = {"keys": sorted(int(keys[i]) for i in range(nr.value))}
+    for b in (0, 3):
+        out[f"s{b}"] = C.metrics(eps[b:b + 1], O.dy3h_forward(sd, x6[b:b + 1], lvl[b:b + 1], guide[b:b + 1]))
+    return out
+
+
 def main():
     which = sys.argv[1:] or ["ops", "small", "sid", "sampler"]
     print(torch.cuda.get_device_name(0))
@@ -51,6 +76,8 @@ def main():
         run("sampler_step", C.sampler_step_case)
     if "small" in which:
         run("forward SMALL 64x48 B=2 (taps)", C.forward_case, SMALL, 2, 64, 48, [0.0029, 0.6], taps=True)
+    if "sidb4" in which:        # B = 4 at 256^2: the smallest batch at which the persistent kernels engage (4 tiles per CU at 288^2)
+        run("forward SID B=4 256x256", sid_b4)
     if "sid" in which:
         ns = C.build_net(SID)
         run("forward SID 256x256 B=1 (taps)", C.forward_case, SID, 1, 256, 256, [0.2394], seed=21, taps=True, net_sd=ns)

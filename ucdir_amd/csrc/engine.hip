@@ -9,6 +9,7 @@
 #include <mutex>
 #include <set>
 #include <array>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
@@ -198,9 +199,6 @@ static void ensure_kernel_attrs() {
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
     set_lds_attr(flash_attn_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn_kernel<3, true>, fa_lds_bytes(384));
     set_lds_attr(flash_attn_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn_kernel<4, true>, fa_lds_bytes(512));
-    float* sk = nullptr;
-    HIPC(hipMalloc((void**)&sk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));
-    g_splitk_buf[dev] = sk;
     done.insert(dev);
 }
 
@@ -329,11 +327,11 @@ static void launch_halo(const GemmP& p, hipStream_t st) {
     HIPC(hipGetLastError());
 }
 
-static bool g_use_halo = true;
+static std::atomic<bool> g_use_halo{true};
 
 // compute units of the current device (persistent kernels launch one workgroup per CU)
-static int g_wsb = -1;               // -1: environment (UCDIR_WSB), 0 / 1: ucdir_debug_flag("wsb", v): block AKGM kernel also at 8 / 16 channels per group
-static int g_persist_grid = 0;      // > 0: ucdir_debug_flag("persist_grid", n) forces the grid of the persistent kernels (tests: many tiles per workgroup on small inputs)
+static std::atomic<int> g_wsb{-1};             // -1: environment (UCDIR_WSB), 0 / 1: ucdir_debug_flag("wsb", v): block AKGM kernel also at 8 / 16 channels per group
+static std::atomic<int> g_persist_grid{0};     // > 0: ucdir_debug_flag("persist_grid", n) forces the grid of the persistent kernels (tests: many tiles per workgroup on small inputs)
 static int num_cus() {
     if (g_persist_grid > 0) return g_persist_grid;
     static std::map<int, int> memo;
@@ -358,12 +356,16 @@ static float* splitk_scratch() {
     int dev = 0;
     HIPC(hipGetDevice(&dev));
     auto it = g_splitk_buf.find(dev);
-    require(it != g_splitk_buf.end(), "split-K scratch not allocated on this device");
-    return it->second;
+    if (it != g_splitk_buf.end()) return it->second;
+    // single-operator entry points only (never captured into a graph): allocated at first use; contexts own their scratch
+    float* sk = nullptr;
+    HIPC(hipMalloc((void**)&sk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));
+    g_splitk_buf[dev] = sk;
+    return sk;
 }
 // number of K splits for a conv3x3_halo grid of `wgs` workgroups over `nchunks` 32-channel chunks (at most 512 workgroups, at
 // least two chunks per split).  UCDIR_SPLITK=0 disables, UCDIR_SPLITK_WGS sets the grid size below which it applies.
-static int g_splitk = -1;           // -1: environment (UCDIR_SPLITK=0 disables), 0 / 1: ucdir_debug_flag("splitk", v)
+static std::atomic<int> g_splitk{-1};         // -1: environment (UCDIR_SPLITK=0 disables), 0 / 1: ucdir_debug_flag("splitk", v)
 static bool splitk_on() {
     static const bool env_on = !(getenv("UCDIR_SPLITK") && atoi(getenv("UCDIR_SPLITK")) == 0);
     return g_splitk < 0 ? env_on : g_splitk != 0;
@@ -650,7 +652,8 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
             const int grid = ntiles < ncu ? ntiles : ncu;
             hipLaunchKernelGGL(akgm_ws_kernel<8>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
         } else if (ws16) {
-            const int ntiles = y.B * p.tiles_x * p.tiles_y, ncu = num_cus() & ~1;
+            int ncu = num_cus() & ~1; if (ncu < 2) ncu = 2;                  // persist_grid = 1 must not give an empty grid (round-3 advice)
+            const int ntiles = y.B * p.tiles_x * p.tiles_y;
             const int grid = 2 * ntiles < ncu ? 2 * ntiles : ncu;            // workgroup pairs: (tile range, channel plane)
             hipLaunchKernelGGL(akgm_ws_kernel<16>, dim3(grid), dim3(HC_THREADS), AkWs::LDS, st, p);
         } else if (pre) {
@@ -728,7 +731,7 @@ struct AttnBufs {
     bool flash = true, half = false;
 };
 
-static int g_flash = -1;            // -1: environment (UCDIR_NO_FLASH), 0 / 1: ucdir_debug_flag("flash", v)
+static std::atomic<int> g_flash{-1};          // -1: environment (UCDIR_NO_FLASH), 0 / 1: ucdir_debug_flag("flash", v)
 static bool flash_ok(int C) {
     static const bool env_on = !getenv("UCDIR_NO_FLASH");
     const bool on = g_flash < 0 ? env_on : g_flash != 0;

@@ -545,8 +545,10 @@ __device__ __forceinline__ void normal4(unsigned long long seed, uint32_t step, 
     philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), step, 0x55434449u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1): 24 bits, never 0 or 1
-        const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        // (0, 1), never 0 or 1: 23 bits + 0.5 is exactly representable in fp32 (24 bits + 0.5 is not above 2^23: it rounded to
+        // even, u could be exactly 1 and the upper half of the grid was coarsened - round-3 advice)
+        const float u1 = ((float)(r[2 * h] >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float u2 = ((float)(r[2 * h + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);
         const float rad = sqrtf(-2.0f * __logf(u1));
         z[2 * h] = rad * __builtin_amdgcn_cosf(u2);                                      // v_cos_f32 / v_sin_f32 take revolutions
         z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);

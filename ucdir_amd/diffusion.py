@@ -115,15 +115,31 @@ class GaussianDiffusion(nn.Module):
             return torch.randn(like.shape, generator=self._gen, device=like.device, dtype=like.dtype)
         return torch.randn_like(like)
 
-    def _start_noise(self, device):
-        """(Re)seed the rank-identical generator at the start of a sampling loop."""
+    def _begin(self):
+        h = getattr(self.denoise_fn, "hold_weight_check", None)
+        if h is not None:
+            h(True)                                           # parameter signature: once per restoration
+
+    def _end(self):
+        """End of every sampler: release the per-restoration buffers the denoiser holds (padded guide windows, gather / paste
+        canvases: hundreds of MB to GBs at full resolution) - not only p_sample_loop's (round-3 advice)."""
+        self._gen = None
+        for name, arg in (("clear_patch_cache", ()), ("hold_weight_check", (False,))):
+            f = getattr(self.denoise_fn, name, None)
+            if f is not None:
+                f(*arg)
+
+    def _start_noise(self, device, kernel_rng=False):
+        """(Re)seed the rank-identical generator at the start of a sampling loop.  ``kernel_rng``: the caller draws its noise inside
+        the update kernel (p_sample_loop without an injected noise source) and needs a seed for it."""
         self._gen = None
         # p_sample_loop draws its noise INSIDE the update kernel (counter-based Philox keyed by (seed, step, element),
         # csrc/misc.hip.h): seed = noise_seed + image offset when set (identical on every rank), else a fresh 63-bit draw from
         # torch's CPU generator (torch.manual_seed still makes a run reproducible).  Injected noise (noise_source) bypasses it.
         if self.noise_seed is not None:
             self._kseed = int(self.noise_seed) + 1000003 * int(self.noise_index)
-        else:
+        elif kernel_rng and self.noise_source is None:
+            # only here: a draw for restorations that never use it would shift the global CPU RNG stream of unrelated code
             self._kseed = int(torch.randint(0, 2 ** 62, (1,)).item())
         if self.noise_seed is not None and self.noise_source is None:
             # noise_index (set by the caller per image, e.g. the dataset index) keeps the noise of different images
@@ -161,7 +177,8 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("unconditional sampling is not part of the UCDIR restoration path")
         x = x_in.contiguous().float()
         sample_inter = 1 | (self.num_timesteps // 10)
-        self._start_noise(x.device)
+        self._begin()
+        self._start_noise(x.device, kernel_rng=True)
         guide = kwargs.get("guide")
         B = x.shape[0]
         if getattr(self.denoise_fn, "use_graph", False) and self._small(x):
@@ -189,23 +206,22 @@ class GaussianDiffusion(nn.Module):
             lvl = torch.empty((B, 1), dtype=torch.float32, device=x.device)
         ret = [x]
         k = 1
-        for i in reversed(range(self.num_timesteps)):
-            level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
-            lvl.fill_(level)
-            eps = self._eps(cond, img, lvl, guide, out=eps_buf)
-            if self.noise_source is not None:
-                noise = self._noise(img, k) if i > 0 else None
-                sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
-            else:                                             # noise of (seed, step k, element) generated in the update kernel
-                sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
-            if i > 0:
-                k += 1
-            if i % sample_inter == 0:
-                ret.append(img.clone())
-        self._gen = None
-        clr = getattr(self.denoise_fn, "clear_patch_cache", None)
-        if clr is not None:
-            clr()                                             # padded guide windows / gather buffers of this restoration
+        try:
+            for i in reversed(range(self.num_timesteps)):
+                level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
+                lvl.fill_(level)
+                eps = self._eps(cond, img, lvl, guide, out=eps_buf)
+                if self.noise_source is not None:
+                    noise = self._noise(img, k) if i > 0 else None
+                    sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
+                else:                                             # noise of (seed, step k, element) generated in the update kernel
+                    sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
+                if i > 0:
+                    k += 1
+                if i % sample_inter == 0:
+                    ret.append(img.clone())
+        finally:
+            self._end()                                       # padded guide windows / gather buffers of this restoration
         if continous:
             return torch.cat(ret, dim=0)
         return ret[-1]
@@ -219,11 +235,19 @@ class GaussianDiffusion(nn.Module):
         times = list(reversed(times.int().tolist()))
         pairs = list(zip(times[:-1], times[1:]))
         ac = self._host_tables["alphas_cumprod"]
+        self._begin()
         self._start_noise(x_in.device)
         img = self._noise(x_in, 0)
         imgs = [img]
         guide = kwargs.get("guide")
         k = 1
+        try:
+            img = self._ddim_steps(x_in, img, imgs, pairs, ac, guide, eta, k)
+        finally:
+            self._end()
+        return img if not continous else torch.stack(imgs, dim=1)
+
+    def _ddim_steps(self, x_in, img, imgs, pairs, ac, guide, eta, k):
         for t, t_next in pairs:
             level, c_recip, c_recipm1, _, _, _ = self.step_coefficients(t)
             lvl = torch.full((x_in.shape[0], 1), level, dtype=torch.float32, device=x_in.device)
@@ -240,7 +264,7 @@ class GaussianDiffusion(nn.Module):
             k += 1
             img = x0 * (an ** 0.5) + c * eps + sigma * noise
             imgs.append(img)
-        return img if not continous else torch.stack(imgs, dim=1)
+        return img
 
     @torch.no_grad()
     def dpm_solver_sample(self, x_in, steps=20, order=2, kwargs={}):
@@ -256,8 +280,12 @@ class GaussianDiffusion(nn.Module):
             lvl = torch.full((B, 1), ns.model_input_time(t), dtype=torch.float32, device=x_in.device)
             return self._eps(x_in, x, lvl, guide)
 
+        self._begin()
         self._start_noise(x_in.device)
-        return D.sample(model_eps, ns, self._noise(x_in, 0), steps=steps, order=order)
+        try:
+            return D.sample(model_eps, ns, self._noise(x_in, 0), steps=steps, order=order)
+        finally:
+            self._end()
 
     @torch.no_grad()
     def sample(self, batch_size=1, continous=False):

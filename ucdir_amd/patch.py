@@ -111,4 +111,6 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
         r, q = divmod(k, per)
         base = (r * per + q) * B
         den[..., a + padding:b - padding, c + padding:d - padding] = allo[base:base + B]
-    return den[..., pd:-pd, pd:-pd]
+    # a fresh tensor, like the reference (utils/util.py:108-146): `den` is a module-owned buffer that the next forward of the
+    # same shape overwrites, so a view into it would silently alias two results (round-3 advice)
+    return den[..., pd:-pd, pd:-pd].clone()

@@ -109,6 +109,15 @@ class DY3h(nn.Module):
         self._wdirty = True                  # parameters changed since the engine packed them
         self._wsig = None                    # signature of the parameter storage the engine packed (see _weights_signature)
         self._gkey = None
+        self._sig_hold = False               # a sampler checked the weight signature for the running restoration (hold_weight_check)
+
+    def hold_weight_check(self, on=True):
+        """Samplers call this at the start (True) and end (False) of a restoration: the parameter signature is evaluated ONCE per
+        restoration instead of at every guide change - in the patch path with more than one chunk per rank the chunk guides
+        alternate, which made it a re-check (two multi-tensor norms + host syncs) per chunk per step (round-3 advice)."""
+        if on and not self._wdirty and self._wsig is not None and self._wsig != self._weights_signature():
+            self._wdirty = True
+        self._sig_hold = bool(on)
 
     def clear_patch_cache(self):
         """Drop the padded guide windows and gather buffers of the last patch-split restoration (hundreds of MB at full size)."""
@@ -202,7 +211,7 @@ class DY3h(nn.Module):
     def prepare_guide(self, guide, pad_mode=1):
         L = _lib.load()
         key = (guide.data_ptr(), guide._version, tuple(guide.shape), tuple(guide.stride()), pad_mode)
-        if key != self._gkey and not self._wdirty and self._wsig != self._weights_signature():
+        if key != self._gkey and not self._sig_hold and not self._wdirty and self._wsig != self._weights_signature():
             self._wdirty = True                 # a parameter was updated in place since the engine packed the weights
         self._sync_weights()
         self._check_dev("guide", guide)
