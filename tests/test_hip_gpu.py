@@ -29,6 +29,23 @@ CROP_TOL = 2.0e-2    # a 3 x 32 x 32 crop of the same forward against the REFERE
 def sid_net():
     return C.build_net(SID)
 
+def _profile_keys(L, fn):
+    """Run fn() with the library's per-launch event profiler on and return {key: launches} of the kernels it dispatched."""
+    import ctypes
+    C.ulib.check(L.ucdir_profile_enable(1))
+    try:
+        r = fn()
+    finally:
+        C.ulib.check(L.ucdir_profile_enable(0))
+    cap = 64
+    keys, ln = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)()
+    ms, fl, by = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+    nr = ctypes.c_int32(0)
+    C.ulib.check(L.ucdir_profile_read(cap, keys, ln, ms, fl, by, ctypes.byref(nr), C._st()))
+    return r, {int(keys[i]): int(ln[i]) for i in range(nr.value)}
+
+
+
 
 @pytest.mark.parametrize("args", [
     (2, 20, 20, 64, 0, 64, 3, 0, False, False, False),     # plain 3x3, TM=64, ragged tile
@@ -71,6 +88,38 @@ def test_conv_persistent(args):
     assert not m["nan"] and m["rel_rms"] < OP_TOL, m
     assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m
     assert m["stats_rel"] < 1e-3, m
+
+
+@pytest.mark.parametrize("args", [
+    # B, H, W, c0, c1, cout, mode, gn, silu, residual, persist_grid
+    (2, 24, 40, 64, 0, 256, 0, True, True, False, 0),       # two row-of-256 units per tile, ragged last tile, GroupNorm fold (all nine border classes)
+    (3, 18, 18, 128, 64, 512, 0, True, True, False, 0),     # cat input, two row tiles, tiles spanning samples (400 positions per sample)
+    (5, 10, 12, 64, 0, 256, 0, True, False, False, 3),      # 3 workgroups: whole units + a stream-K remainder cut across workgroups, several samples per tile
+    (2, 36, 36, 256, 0, 512, 0, True, True, True, 7),       # residual; 7 workgroups: units cut into three parts (finish kernel sums in workgroup order)
+    (2, 16, 24, 128, 0, 256, 2, False, False, False, 0),    # Upsample: four parity classes of 2 x 2 taps
+    (3, 9, 9, 256, 0, 512, 2, False, False, False, 5),      # Upsample, stream-K across parity classes and row tiles
+    (1, 72, 72, 96, 32, 256, 0, True, True, False, 0),      # chunk count 4 with the concatenation boundary inside (c0 = 96 = 3 chunks)
+    (16, 18, 18, 512, 0, 512, 0, True, True, False, 0),     # the 18^2 level of the bench configuration
+], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16"])
+def test_conv_stream_k(args):
+    """conv_sk_kernel (persistent stream-K 3x3 conv / Upsample parity classes on 256-row x 256-position linear tiles) + its finish
+    kernel against torch through the C ABI: batch-flattened tiles (borders computed and dropped, tiles crossing samples), per-sample
+    GroupNorm fold in the epilogue, fixed-order partial sums, statistics."""
+    B, H, W, c0, c1, cout, mode, gn, silu, residual, grid = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"convsk", 1))
+    C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    try:
+        (m, keys) = _profile_keys(L, lambda: C.conv_case(B, H, W, c0, c1, cout, 3, mode, gn, silu, residual, seed=5))
+        m2 = C.conv_case(B, H, W, c0, c1, cout, 3, mode, gn, silu, residual, seed=5)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+        C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
+    assert (126 if mode == 2 else 125) in keys, keys                # the stream-K kernel ran, not a fallback
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m
+    assert m["stats_rel"] < 1e-3, m
+    assert m2["rel_rms"] == m["rel_rms"] and m2["max_abs"] == m["max_abs"] and m2["stats_rel"] == m["stats_rel"], (m, m2)   # run to run
 
 
 @pytest.mark.parametrize("args", [
@@ -331,21 +380,6 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
     m = C.metrics(a[5:6], one.cpu())
     assert m["rel_rms"] < FWD_TOL, m
 
-
-def _profile_keys(L, fn):
-    """Run fn() with the library's per-launch event profiler on and return {key: launches} of the kernels it dispatched."""
-    import ctypes
-    C.ulib.check(L.ucdir_profile_enable(1))
-    try:
-        r = fn()
-    finally:
-        C.ulib.check(L.ucdir_profile_enable(0))
-    cap = 64
-    keys, ln = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)()
-    ms, fl, by = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
-    nr = ctypes.c_int32(0)
-    C.ulib.check(L.ucdir_profile_read(cap, keys, ln, ms, fl, by, ctypes.byref(nr), C._st()))
-    return r, {int(keys[i]): int(ln[i]) for i in range(nr.value)}
 
 
 @pytest.mark.parametrize("B", [8, 16])

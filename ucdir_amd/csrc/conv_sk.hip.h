@@ -1,0 +1,484 @@
+// 3x3 stride-1 convolution (and the parity classes of Upsample + conv3x3) as a PERSISTENT stream-K kernel on 256-row tiles (gfx950).
+//
+// conv3x3_halo_kernel<128> (128 rows x 256 pixels per workgroup, 64 x 64 wave tiles, two workgroups per CU) sits at the ceiling of
+// its structure: one LDS fragment read per MFMA, 16 MFMAs between two barriers, a prologue / epilogue bubble per workgroup and whole
+// rounds of workgroups (round-3 verdict: 0.32 of the MFMA peak for 38 % of the forward).  This kernel is the structural step:
+//   * ONE workgroup (8 wave64) per CU walks work units; a unit = MW x 128 output rows x NPX = 512 / MW pixel positions
+//     (MW = 2: 256 x 256, C_out multiples of 256; MW = 1: 128 x 512, C_out = 128); a wave owns 128 rows x 64 pixels = 4 x 2 MFMA
+//     tiles of 32 x 32 x 16 - 128 accumulator registers, SIX fragment reads per EIGHT MFMAs (0.75 instead of 1.0);
+//   * pixel tiles are LINEAR in the zero-bordered [B][H + 2][W + 2] position space, batch-flattened: a tile is NPX consecutive
+//     positions (crossing rows and samples), its halo the NPX + 2 Wp + 2 positions around them - one contiguous range of the
+//     tensor.  Tap (ky, kx) of slot s is halo position s + ky Wp + kx: a uniform shift, 16 consecutive lanes always read 16
+//     consecutive halo positions (conflict-free ds_read_b128 at any width), border positions are computed and not stored
+//     (utilisation H W / ((H + 2)(W + 2)): 95 % at 72^2, 90 % at 36^2, 81 % at 18^2 - the 2-D tiles of conv3x3_halo reach 84 / 84 /
+//     63 %); per-sample GroupNorm statistics enter in the EPILOGUE (rstd, mean * rstd per lane), so a tile may span samples;
+//   * K advances one tap x 32 channels per sub-step (16 MFMAs per wave, two k16 units); the weights are packed on the host as the
+//     LDS image of every sub-step (16 KB, fragment-major: a fragment read is 1 KB lane-linear, conflict-free, and every LDS-DMA
+//     piece is 1 KB of contiguous memory) and stream through a FOUR-deep ring: the stage of sub-step h + 4 is requested at sub-step
+//     h and waited for (counted vmcnt) at h + 2, one sub-step before its first read - fragment reads run two units ahead ACROSS the
+//     one barrier per sub-step, which only protects the ring slot being refilled;
+//   * the halo of the next 32-channel chunk arrives under the current chunk (double buffer, 64-byte pixels, 16-byte chunk
+//     XOR (position >> 2) & 3 on the DMA's source side);
+//   * stream-K: the units that do not fill a whole round of workgroups are cut into chunk ranges dealt evenly to ALL workgroups;
+//     a partial unit leaves raw fp32 accumulators (accumulator layout, coalesced 16-byte stores) in a scratch slot and
+//     conv_sk_finish_kernel sums the parts in ascending workgroup order (fixed: bit-reproducible) and runs the same epilogue;
+//   * epilogue in registers: rows are permuted at pack time so that a lane holds 16 consecutive channels of one pixel per MFMA tile
+//     (32-byte pieces); GroupNorm fold from two sample-independent tables in LDS (bias + Tb, Tg; 9 border classes) and the
+//     per-sample (rstd, mean * rstd) list built once per workgroup; output statistics as 2^-20 fixed-point integers.
+// Reference: model/ucdir.py:110 (block conv1), :57 (Upsample conv), SURVEY.md Appendix A.
+#pragma once
+#include "conv_halo.hip.h"
+#include "akgm_ws.hip.h"
+
+struct ConvSkP {
+    const bf16_t* A; long long a_par_stride;          // stage images [parity][row tile][chunk][tap][MW * 8 KB]; elements per parity class
+    const bf16_t* B0; const bf16_t* B1; int c0, ld0, ld1;   // input(s), zero-bordered NHWC; channels [0, c0) from B0, the rest from B1
+    int nchunks;                                      // 32-channel chunks = C_in / 32
+    int nb, H, W, Wp, HpWp, npos;                     // input grid (= output grid; low-res grid for the Upsample parity classes)
+    int ntiles, rowtiles, npar;                       // pixel tiles, row tiles, parity classes (1 | 4); units = npar * rowtiles * ntiles
+    int nhp;                                          // halo DMA pieces (16 positions each) per chunk
+    int nfeat;
+    float alpha; int fold; int act;
+    const stat_t* stats0; const stat_t* stats1; double inv_count;
+    const float* bias; const float* Tb; const float* Tg; int tab_ld;
+    const bf16_t* res; int res_ld;
+    bf16_t* out; int out_ld;
+    stat_t* stats_out;
+    // schedule: units [0, ndp) whole, round-robin over the grid; units [ndp, units) cut into chunk ranges over all workgroups
+    int units, ndp;
+    float* partial;                                   // [2 * grid][MW * 32768] fp32: slot 2 g = workgroup g's first partial segment, 2 g + 1 its last
+    unsigned long long* dbg;
+};
+
+template <int MW>
+struct CvSk {
+    static constexpr int NPX = 512 / MW;              // pixel positions per unit
+    static constexpr int ROWS = 128 * MW;
+    static constexpr int STAGE = 8192 * MW;           // bytes of one sub-step's weights
+    static constexpr int PW = MW;                     // DMA pieces per wave and stage
+    static constexpr int OFF_W = 0;
+    static constexpr int OFF_TB = 4 * STAGE;          // [9][ROWS] fp32: bias + Tb[cls]
+    static constexpr int OFF_TG = OFF_TB + 9 * ROWS * 4;
+    static constexpr int OFF_MS = OFF_TG + 9 * ROWS * 4;     // [64][2] fp32: (alpha * rstd, mean * rstd) per sample
+    static constexpr int MAXB = 64;
+    static constexpr int OFF_DUMMY = OFF_MS + MAXB * 8;      // landing zone of the DMA pieces issued past the end of a segment (keeps the counted waits uniform)
+    static constexpr int OFF_H = OFF_DUMMY + 1024;           // two halo buffers of nhp KB each
+    static constexpr int THREADS = 512;
+    static constexpr int NHW = MW == 2 ? 4 : 7;       // halo DMA pieces per wave and chunk (a fixed number: the counted waits are literals);
+    static constexpr int NHP_MAX = 8 * NHW;           // pieces past the halo's end repeat its last piece
+    __host__ __device__ static constexpr int lds_bytes(int nhp) { return OFF_H + 2 * nhp * 1024; }
+    __host__ __device__ static constexpr int part_floats() { return ROWS * NPX; }
+};
+
+#ifdef UCDIR_TIMING
+#define SK_STAMP() do { if (dbg_on && dbg_n < 250) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SK_STAMP() do {} while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ void sk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// segment list of workgroup g: its whole units (round-robin) and its chunk range of the stream-K part
+struct SkSched {
+    int units, ndp, nch, G;
+    long long tc;                                      // chunks of the stream-K part
+    __host__ __device__ SkSched(int units_, int ndp_, int nch_, int G_) : units(units_), ndp(ndp_), nch(nch_), G(G_), tc((long long)(units_ - ndp_) * nch_) {}
+    __host__ __device__ long long start(int g) const { return tc * g / G; }
+};
+
+// epilogue of one wave's 128 x 64 tile from its accumulators: GroupNorm fold, activation, residual, statistics, bf16 NHWC store.
+// Shared by the conv kernel and the finish kernel (identical arithmetic: a unit finished in-kernel or from partial tiles gives the
+// same bits for the same accumulator values).
+template <int MW>
+__device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, f32x16_t (&acc)[4][2], int par, int rt, int tile,
+                                            int wm, int wn, int lane) {
+    using L = CvSk<MW>;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const float* tb = reinterpret_cast<const float*>(smem + L::OFF_TB);
+    const float* tg = reinterpret_cast<const float*>(smem + L::OFF_TG);
+    const float* ms = reinterpret_cast<const float*>(smem + L::OFF_MS);
+    const int act = p.act;
+    const int py = par >> 1, pxp = par & 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int q = tile * L::NPX + wn * 64 + n * 32 + l31;          // position in [B][H + 2][W + 2]
+        const int b = q / p.HpWp, r = q - b * p.HpWp;
+        const int yp = r / p.Wp, xp = r - yp * p.Wp;
+        const bool valid = q < p.npos && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
+        const int bb = b < p.nb ? b : p.nb - 1;
+        const float ra = ms[2 * bb], mr = ms[2 * bb + 1];
+        const int y = yp - 1, x = xp - 1;
+        const int cls = p.npar > 1 ? 4 : (y <= 0 ? 0 : (y >= p.H - 1 ? 2 : 1)) * 3 + (x <= 0 ? 0 : (x >= p.W - 1 ? 2 : 1));
+        long long opos = q;
+        if (p.npar > 1) opos = ((long long)b * (2 * p.H + 2) + (2 * y + py + 1)) * (2 * p.W + 2) + (2 * x + pxp + 1);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ch = wm * 128 + f * 32 + 16 * hh;                // channel within the row tile
+            float v[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(tb + cls * L::ROWS + ch + 4 * g4);
+                const f32x4_t g4v = *reinterpret_cast<const f32x4_t*>(tg + cls * L::ROWS + ch + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g4 + e] = fmaf(acc[f][n][4 * g4 + e], ra, fmaf(-mr, g4v[e], b4[e]));
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = silu_fast(v[i]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
+            }
+            const int fo = rt * L::ROWS + ch;
+            if (valid && fo < p.nfeat) {
+                if (p.res) {
+                    const uint4 r0 = *reinterpret_cast<const uint4*>(p.res + opos * p.res_ld + fo);
+                    const uint4 r1 = *reinterpret_cast<const uint4*>(p.res + opos * p.res_ld + fo + 8);
+                    const bf16_t* h0 = reinterpret_cast<const bf16_t*>(&r0);
+                    const bf16_t* h1 = reinterpret_cast<const bf16_t*>(&r1);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { v[i] += bf2f(h0[i]); v[8 + i] += bf2f(h1[i]); }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+                bf16_t* op = p.out + opos * p.out_ld + fo;
+                *reinterpret_cast<uint4*>(op) = pack8_bf16(v);
+                *reinterpret_cast<uint4*>(op + 8) = pack8_bf16(v + 8);
+            }
+        }
+        if (p.stats_out) {
+            // per-sample sums: the 32 positions of this MFMA tile usually belong to one sample; loop over the few they can span
+            const int b_lo = __builtin_amdgcn_readlane(b, 0), b_hi0 = __builtin_amdgcn_readlane(b, 31);
+            const int b_hi = b_hi0 < p.nb ? b_hi0 : p.nb - 1;
+            const stat_t f1 = valid ? stat_fx((double)s1) : 0, f2 = valid ? stat_fx((double)s2) : 0;
+            for (int sb = b_lo; sb <= b_hi; ++sb) {
+                const stat_t a = wave_sum_ll(b == sb ? f1 : 0), q2 = wave_sum_ll(b == sb ? f2 : 0);
+                if (lane == 0 && (a != 0 || q2 != 0)) stat_add_fx(p.stats_out, sb, a, q2);
+            }
+        }
+    }
+}
+
+// per-workgroup tables: (alpha * rstd, mean * rstd) of every sample; then (bias + Tb, Tg) of a row tile
+template <int MW>
+__device__ __forceinline__ void sk_sample_table(const ConvSkP& p, unsigned char* smem, int wave, int lane) {
+    using L = CvSk<MW>;
+    float* ms = reinterpret_cast<float*>(smem + L::OFF_MS);
+    for (int b = wave; b < p.nb; b += 8) {
+        float mean = 0.f, rstd = 1.f;
+        if (p.fold) {
+            long long v = 0;
+            if (lane < 2 * UCDIR_STAT_SLOTS) {
+                v = p.stats0[(long long)b * (2 * UCDIR_STAT_SLOTS) + lane];
+                if (p.stats1) v += p.stats1[(long long)b * (2 * UCDIR_STAT_SLOTS) + lane];
+            }
+#pragma unroll
+            for (int off = 2; off < 2 * UCDIR_STAT_SLOTS; off <<= 1) v += __shfl_xor(v, off);
+            const long long q = __shfl(v, 1);
+            mean_rstd(stat_val(v), stat_val(q), p.inv_count, mean, rstd);
+        }
+        if (lane == 0) { ms[2 * b] = p.alpha * rstd; ms[2 * b + 1] = p.fold ? mean * rstd : 0.f; }
+    }
+}
+template <int MW>
+__device__ __forceinline__ void sk_row_table(const ConvSkP& p, unsigned char* smem, int rt, int tid) {
+    using L = CvSk<MW>;
+    float* tb = reinterpret_cast<float*>(smem + L::OFF_TB);
+    float* tg = reinterpret_cast<float*>(smem + L::OFF_TG);
+    for (int i = tid; i < 9 * L::ROWS; i += L::THREADS) {
+        const int cls = i / L::ROWS, fl = i - cls * L::ROWS, f = rt * L::ROWS + fl;
+        float vb = 0.f, vg = 0.f;
+        if (f < p.nfeat) {
+            vb = p.bias ? p.bias[f] : 0.f;
+            if (p.fold) { vb += p.Tb[(long long)cls * p.tab_ld + f]; vg = p.Tg[(long long)cls * p.tab_ld + f]; }
+        }
+        tb[i] = vb; tg[i] = vg;
+    }
+}
+
+template <int MW, int NTAPS>
+__global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
+    using L = CvSk<MW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWN = 8 / MW;                                      // waves along the pixel dimension
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
+    int dbg_n = 0;
+#endif
+    SK_STAMP();
+    const int G = gridDim.x;
+    const int Wp = p.Wp, nch = p.nchunks, nhp = p.nhp;
+    const int HB = nhp * 1024;                                       // bytes of one halo buffer
+    constexpr int NHW = L::NHW;                                      // halo pieces per wave and chunk
+    constexpr int TA = NTAPS - 3 > 1 ? NTAPS - 3 : 1;                // sub-steps of a chunk whose S point may carry halo pieces: the
+                                                                     // next chunk's first fragment reads are issued behind S(NTAPS - 2), whose
+                                                                     // wait covers everything requested up to S(NTAPS - 4)
+    constexpr int HPER = (NHW + TA - 1) / TA;                        // pieces per such S point
+
+    sk_sample_table<MW>(p, smem, wave, lane);
+
+    // ---- per-lane constants of the fragment reads ------------------------------------------------------------------------
+    // A: stage slot s, fragment f (32 rows), k16 j: 1 KB lane-linear at s * STAGE + ((4 wm + f) * 2 + j) * 1024 + lane * 16
+    const unsigned a_lane = L::OFF_W + (4 * wm) * 2048 + lane * 16;
+    // B: tap t, MFMA tile n: halo position hp = 64 wn + 32 n + l31 + ky Wp + kx; 64 bytes per position, 16-byte chunk
+    // (2 jj + hh) ^ ((hp >> 2) & 3): address(jj = 1) = address(jj = 0) ^ 32
+    unsigned bx[NTAPS][2];
+    const int par_of = 0;
+    (void)par_of;
+
+    // ---- halo staging geometry: piece i = 16 positions; lane -> (position 16 i + lane / 4, physical chunk lane & 3) -----------
+    // (source offsets are per tile; see tile_setup)
+    const SkSched sch(p.units, p.ndp, nch, G);
+    const long long c_beg = sch.start(lid), c_end = sch.start(lid + 1);      // stream-K chunk range of this workgroup
+    const int ndp_mine = lid < p.ndp ? (p.ndp - lid + G - 1) / G : 0;        // whole units g, g + G, ...
+
+    int rt_cur = -1;
+    int seg = 0;                                                             // segment counter (partial-slot choice)
+    long long cpos = c_beg;
+    int dpi = 0;
+#pragma unroll 1
+    while (true) {
+        // ---- next segment: (unit, chunk range) ----------------------------------------------------------------------------
+        int unit, cb, ce;
+        bool first_sk = false;
+        if (dpi < ndp_mine) { unit = lid + dpi * G; cb = 0; ce = nch; ++dpi; }
+        else if (cpos < c_end) {
+            const long long u = cpos / nch;
+            unit = p.ndp + (int)u; cb = (int)(cpos - u * nch);
+            const long long e = (u + 1) * nch < c_end ? (u + 1) * nch : c_end;
+            ce = (int)(e - u * nch);
+            first_sk = cpos == c_beg;
+            cpos = e;
+        } else break;
+        const bool whole = cb == 0 && ce == nch;
+        int par = 0, rt, tile;
+        {
+            int u = unit;
+            const int per_par = p.rowtiles * p.ntiles;
+            if (p.npar > 1) { par = u / per_par; u -= par * per_par; }
+            rt = u / p.ntiles; tile = u - rt * p.ntiles;
+        }
+        const int py = par >> 1, pxp = par & 1;
+        __syncthreads();                                             // everybody is done with the previous segment's LDS (tables, ring, halo)
+        if (rt != rt_cur) { sk_row_table<MW>(p, smem, rt, tid); rt_cur = rt; }
+
+        // ---- tile geometry -------------------------------------------------------------------------------------------------
+        const int q0 = tile * L::NPX;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            int ky, kx;
+            if (NTAPS == 9) { ky = t / 3; kx = t - 3 * ky; } else { ky = py + (t >> 1); kx = pxp + (t & 1); }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int hp = wn * 64 + n * 32 + l31 + ky * Wp + kx;
+                bx[t][n] = L::OFF_H + (hp << 6) + (((hh ^ (hp >> 2)) & 3) << 4);
+            }
+        }
+        // halo pieces of this wave: j-th piece = piece j * 8 + wave (clamped: a repeat of the last piece is harmless)
+        unsigned hq[NHW], hsw[NHW]; int hdst[NHW];
+#pragma unroll
+        for (int j = 0; j < NHW; ++j) {
+            int i = j * 8 + wave; i = i < nhp ? i : nhp - 1;
+            const int pos = 16 * i + (lane >> 2);
+            int q = q0 - Wp - 1 + pos;
+            q = q < 0 ? 0 : (q >= p.npos ? p.npos - 1 : q);
+            hq[j] = (unsigned)q; hsw[j] = (unsigned)(((lane & 3) ^ ((pos >> 2) & 3)) << 3);
+            hdst[j] = i * 1024;
+        }
+        auto issue_halo = [&](int c, int j, bool real) {         // piece j of chunk c into buffer (c - cb) & 1
+            int ch = c * 32;
+            const bf16_t* src; int ld;
+            if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
+            const unsigned off = hq[j] * (unsigned)ld + hsw[j] + (unsigned)ch;
+            unsigned char* dst = real ? smem + L::OFF_H + ((c - cb) & 1) * HB + hdst[j] : smem + L::OFF_DUMMY;
+            stage16(src + off, dst, lane);
+        };
+        // weights: stage k of this (parity, row tile) at A + ((par * rowtiles + rt) * nch * NTAPS + k) * STAGE / 2 elements
+        const bf16_t* const a_tile = p.A + (long long)par * p.a_par_stride + ((long long)rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512 + lane * 8;
+        const int k_end = ce * NTAPS;
+        auto issue_stage = [&](int k, int slot) {
+            const bool real = k < k_end;
+            const bf16_t* src = a_tile + (long long)(real ? k : k_end - 1) * (L::STAGE / 2);
+#pragma unroll
+            for (int j = 0; j < L::PW; ++j)
+                stage16(src + j * 512, real ? smem + L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024 : smem + L::OFF_DUMMY, lane);
+        };
+
+        f32x16_t acc[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[f][n][e] = 0.f;
+
+        // ---- prologue: halo of chunk cb, stages 0 .. 3 --------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < NHW; ++j) issue_halo(cb, j, true);
+        {
+            const int k0 = cb * NTAPS;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) issue_stage(k0 + s, s);
+        }
+        HC_WAIT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        SK_STAMP();
+
+        bf16x8_t fa[2][4], fb[2][2];
+        // R(t, jj) of sub-step h: A from slot h & 3, B from the halo buffer of its chunk (bx[][] is kept at the CURRENT chunk's buffer)
+        auto reads = [&](auto tc, auto jc, int h, unsigned boff) {
+            constexpr int t = decltype(tc)::value, jj = decltype(jc)::value;
+            const unsigned aa = a_lane + (unsigned)((h & 3) * L::STAGE);
+            lds_read16_asm<0 * 2048 + jj * 1024>(fa[jj][0], aa);
+            lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aa);
+            lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aa);
+            lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aa);
+            const unsigned b0 = (bx[t][0] + boff) ^ (jj << 5), b1 = (bx[t][1] + boff) ^ (jj << 5);
+            lds_read16_asm<0>(fb[jj][0], b0);
+            lds_read16_asm<0>(fb[jj][1], b1);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // nothing of the compiler's own is in the LDS / scalar queue from here on
+        __builtin_amdgcn_sched_barrier(0);
+        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, 0u);
+        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, 0u);
+
+        int h = 0;                                                   // sub-step counter of this segment
+        unsigned bcur = 0;                                           // halo buffer offset of the current chunk (0 | HB)
+#pragma unroll 1
+        for (int c = cb; c < ce; ++c) {
+            const unsigned bnext = bcur ? 0u : (unsigned)HB;
+            static_for<0, NTAPS>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int tn = (t + 1) % NTAPS;
+                constexpr int tm1 = (t + NTAPS - 1) % NTAPS;
+                // ---- unit (t, 0) ----
+                lgkm_wait_asm<6>();                                  // R(t, 0) landed (R(t, 1) may be in flight)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][f], fb[0][n], acc[f][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                reads(std::integral_constant<int, tn>{}, std::integral_constant<int, 0>{}, h + 1, tn == 0 ? bnext : bcur);
+                // ---- unit (t, 1) ----
+                lgkm_wait_asm<6>();                                  // R(t, 1) landed: every read of stage h is complete
+                {
+                    // S point: stage h + 2 must be in LDS (requested two sub-steps ago); allowed in flight: the halo pieces of S(t - 1) and stage h + 3
+                    constexpr int j0p = tm1 * HPER < NHW ? tm1 * HPER : NHW, j1p = (tm1 + 1) * HPER < NHW ? (tm1 + 1) * HPER : NHW;
+                    constexpr int c1 = tm1 < TA ? j1p - j0p : 0;      // halo pieces S(t - 1) issued
+                    sk_wait_vm<L::PW + c1>();
+                    asm volatile("s_barrier" ::: "memory");
+                    if constexpr (t < TA) {
+                        constexpr int j0 = t * HPER < NHW ? t * HPER : NHW, j1 = (t + 1) * HPER < NHW ? (t + 1) * HPER : NHW;
+                        const bool more = c + 1 < ce;
+                        static_for<j0, j1>([&](auto jc) { issue_halo(more ? c + 1 : c, decltype(jc)::value, more); });
+                    }
+                    issue_stage(cb * NTAPS + h + 4, h & 3);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][f], fb[1][n], acc[f][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                reads(std::integral_constant<int, tn>{}, std::integral_constant<int, 1>{}, h + 1, tn == 0 ? bnext : bcur);
+                ++h;
+            });
+            bcur = bnext;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(fa[jj][f]));
+            asm volatile("" : "+v"(fb[jj][0]), "+v"(fb[jj][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SK_STAMP();
+
+        if (whole) {
+            sk_epilogue<MW>(p, smem, acc, par, rt, tile, wm, wn, lane);
+        } else {
+            // raw accumulators, accumulator layout: [wave][f][n][reg / 4][lane][4] fp32 - coalesced 16-byte stores
+            float* pw = p.partial + ((long long)(2 * lid + (first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(pw + ((f * 2 + n) * 4 + g4) * 256) =
+                            make_float4(acc[f][n][4 * g4], acc[f][n][4 * g4 + 1], acc[f][n][4 * g4 + 2], acc[f][n][4 * g4 + 3]);
+        }
+        SK_STAMP();
+        ++seg;
+    }
+#ifdef UCDIR_TIMING
+    if (dbg_on) p.dbg[255] = dbg_n;
+#endif
+}
+
+// Second half of a stream-K launch: one workgroup per cut unit sums the partial tiles in ascending workgroup order and runs the
+// epilogue.  grid = number of stream-K units; units that one workgroup computed whole exit at once.
+template <int MW>
+__global__ __launch_bounds__(512, 2) void conv_sk_finish_kernel(const ConvSkP p, int G) {
+    using L = CvSk<MW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWN = 8 / MW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int nch = p.nchunks;
+    const SkSched sch(p.units, p.ndp, nch, G);
+    const int u = blockIdx.x;                                        // stream-K unit index
+    const long long a = (long long)u * nch, b = a + nch;             // its chunk range
+    // workgroups whose range meets [a, b): the first is the one that holds chunk a
+    int g = (int)((a * G + G - 1) / sch.tc);                         // smallest g with start(g + 1) > a: search around the estimate
+    if (g >= G) g = G - 1;
+    while (g > 0 && sch.start(g) > a) --g;
+    while (sch.start(g + 1) <= a) ++g;
+    if (sch.start(g) <= a && sch.start(g + 1) >= b) return;          // computed whole by one workgroup
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[f][n][e] = 0.f;
+    sk_sample_table<MW>(p, smem, wave, lane);
+    int par = 0, rt, tile;
+    {
+        int uu = p.ndp + u;
+        const int per_par = p.rowtiles * p.ntiles;
+        if (p.npar > 1) { par = uu / per_par; uu -= par * per_par; }
+        rt = uu / p.ntiles; tile = uu - rt * p.ntiles;
+    }
+    sk_row_table<MW>(p, smem, rt, tid);
+    for (; g < G && sch.start(g) < b; ++g) {
+        if (sch.start(g + 1) <= a) continue;
+        const bool first = sch.start(g) >= a;                        // this unit holds the workgroup's first chunk: its first segment
+        const float* pr = p.partial + ((long long)(2 * g + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4*>(pr + ((f * 2 + n) * 4 + g4) * 256);
+                    acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w;
+                }
+    }
+    __syncthreads();
+    sk_epilogue<MW>(p, smem, acc, par, rt, tile, wm, wn, lane);
+}

@@ -22,6 +22,7 @@
 #include "akgm_ws.hip.h"
 #include "akgm_ws32.hip.h"
 #include "conv_ws.hip.h"
+#include "conv_sk.hip.h"
 #include "conv_ws128.hip.h"
 #include "flash_attn.hip.h"
 #include "qkv_ws.hip.h"
@@ -104,6 +105,8 @@ struct ConvW {
     bf16_t* Aws128 = nullptr;                            // 3x3 128 -> 64 + res_conv: A fragments of conv_ws128_kernel (72 steps, then the res_conv's 8)
     bf16_t* Aqkv = nullptr;                              // 1x1 C -> 3C of SelfAttention: fragments of qkv_ws_kernel (qkv_ws.hip.h)
     bf16_t* Atile = nullptr;                             // 3x3: the weight stages of conv3x3_halo_kernel<TM> as contiguous 16 KB blocks (pack_conv_tiled)
+    bf16_t* Ask = nullptr; bf16_t* Ask_up = nullptr;     // 3x3 / Upsample parity classes: stage images of conv_sk_kernel (pack_conv_sk); sk_mw rows of 128 per tile
+    int sk_mw = 0; long long sk_up_stride = 0;
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -125,12 +128,19 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
     if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
     if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && P.rows_pad % W.TM == 0) W.Atile = pool.upload(pack_conv_tiled(P, W.TM));
+    if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && cout % 256 == 0) { W.sk_mw = 2; W.Ask = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 2)); }
     if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
 }
 static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
     PackedConv P = pack_upconv(w, bias, W.cout, W.cin, W.TM);
     W.Aup = pool.upload(P.A); W.Kup = P.Kpad;
+    if (W.cin % 32 == 0 && W.cout % 256 == 0) {
+        W.sk_mw = 2;
+        std::vector<bf16_t> img = pack_conv_sk(P.A, 4, P.rows_pad, P.Kpad, W.cin, 4, 2);
+        W.sk_up_stride = (long long)(img.size() / 4);
+        W.Ask_up = pool.upload(img);
+    }
 }
 static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
     PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, 0);
@@ -175,6 +185,8 @@ template <int TM> static void set_cgemm_attrs() {
     set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024);
 }
 #define SPLITK_MAX_WGS 512
+#define SK_MAX_GRID 256                            // conv_sk_kernel: two partial slots of 256 KB per workgroup
+#define SCRATCH_BYTES ((size_t)2 * SK_MAX_GRID * 65536 * sizeof(float))   // >= SPLITK_MAX_WGS * 256 * 128 floats (conv3x3_halo split-K)
 static std::map<int, float*> g_splitk_buf;     // split-K scratch per device for the single-operator entry points (contexts own theirs)
 static std::mutex g_static_mu;                 // the process-global memos below (attribute set, scratch map, tile / CU-count memos)
 static void ensure_kernel_attrs() {
@@ -194,6 +206,8 @@ static void ensure_kernel_attrs() {
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
+    set_lds_attr(conv_sk_kernel<2, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 4>, 160 * 1024);
+    set_lds_attr(conv_sk_finish_kernel<2>, CvSk<2>::lds_bytes(0));
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -359,7 +373,7 @@ static float* splitk_scratch() {
     if (it != g_splitk_buf.end()) return it->second;
     // single-operator entry points only (never captured into a graph): allocated at first use; contexts own their scratch
     float* sk = nullptr;
-    HIPC(hipMalloc((void**)&sk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));
+    HIPC(hipMalloc((void**)&sk, SCRATCH_BYTES));
     g_splitk_buf[dev] = sk;
     return sk;
 }
@@ -399,6 +413,91 @@ static int choose_usplit(int nblk) {
         if (cost < best - 1e-9) { best = cost; best_us = us; }
     }
     return best_us;
+}
+
+// ---- conv_sk_kernel (conv_sk.hip.h): persistent stream-K 3x3 conv / Upsample parity classes on 256-row tiles -------------------------
+static std::atomic<int> g_convsk{-1};          // -1: environment (UCDIR_NO_CONV_SK) + work threshold, 0: off, 1: forced (tests: any size)
+static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st) {
+    static const bool env_on = !getenv("UCDIR_NO_CONV_SK");
+    const int mode = g_convsk.load();
+    if (mode == 0 || (mode < 0 && !env_on)) return false;
+    const bf16_t* img = upph ? w.Ask_up : w.Ask;
+    if (!img || w.sk_mw != 2) return false;
+    const int cin = x0.C + (x1 ? x1->C : 0);
+    if (x0.C % 32 || (x1 && x1->C % 32) || y.C % 8) return false;
+    const int H = x0.H, W = x0.W, Wp = W + 2, HpWp = (H + 2) * Wp, B = x0.B;
+    if (B > CvSk<2>::MAXB) return false;
+    const long long npos = (long long)B * HpWp;
+    if (npos * (long long)(cin > y.C ? cin : y.C) * (upph ? 4 : 1) >= (1LL << 31)) return false;      // 32-bit element offsets in the kernel
+    const int NPX = CvSk<2>::NPX;
+    const int nhp = (NPX + 2 * Wp + 2 + 15) / 16;
+    if (CvSk<2>::lds_bytes(nhp) > 160 * 1024) return false;
+    const int ntaps = upph ? 4 : 9;
+    (void)ntaps;
+    if (nhp > CvSk<2>::NHP_MAX) return false;                                                        // fixed halo piece count per wave
+    ConvSkP p; std::memset(&p, 0, sizeof(p));
+    p.A = img; p.a_par_stride = upph ? w.sk_up_stride : 0;
+    p.B0 = x0.p; p.ld0 = x0.C; p.c0 = x0.C;
+    if (x1) { p.B1 = x1->p; p.ld1 = x1->C; }
+    p.nchunks = cin / 32;
+    p.nb = B; p.H = H; p.W = W; p.Wp = Wp; p.HpWp = HpWp; p.npos = (int)npos;
+    p.ntiles = (int)((npos + NPX - 1) / NPX); p.rowtiles = (w.cout + 255) / 256; p.npar = upph ? 4 : 1;
+    p.nhp = nhp; p.nfeat = w.cout;
+    p.alpha = 1.f; p.fold = (!upph && w.fold) ? 1 : 0; p.act = act;
+    if (p.fold) {
+        p.stats0 = x0.stats; p.stats1 = x1 ? x1->stats : nullptr;
+        p.inv_count = 1.0 / ((double)cin * H * W);
+        p.Tb = w.Tb; p.Tg = w.Tg; p.tab_ld = w.cout;
+    }
+    p.bias = w.bias;
+    if (res) { p.res = res->p; p.res_ld = res->C; }
+    p.out = y.p; p.out_ld = y.C;
+    if (want_stats) p.stats_out = y.stats;
+    p.units = p.npar * p.rowtiles * p.ntiles;
+    int G = num_cus(); if (G > SK_MAX_GRID) G = SK_MAX_GRID;
+    const long long work = (long long)p.units * p.nchunks;           // chunks of 9 (4) sub-steps
+    if (mode < 0 && (work < 3LL * G || p.units * 8 < G)) return false;   // too little for one workgroup per CU: the one-shot kernels (split-K) are faster
+    if (G > p.units * p.nchunks) G = (int)(p.units * p.nchunks);
+    p.ndp = (p.units / G) * G;
+    p.partial = splitk_scratch();
+    const size_t lds = CvSk<2>::lds_bytes(nhp);
+    const int nsk = p.units - p.ndp;
+    auto go = [&]() {
+        if (upph) hipLaunchKernelGGL((conv_sk_kernel<2, 4>), dim3(G), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_sk_kernel<2, 9>), dim3(G), dim3(512), lds, st, p);
+        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<2>), dim3(nsk), dim3(512), CvSk<2>::lds_bytes(0), st, p, G);
+    };
+#ifdef UCDIR_TIMING
+    {
+        static unsigned long long* dbgbuf = nullptr;
+        if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
+        HIPC(hipMemset(dbgbuf, 0, 256 * 8));
+        p.dbg = dbgbuf;
+        go();
+        unsigned long long h[256];
+        HIPC(hipStreamSynchronize(st));
+        HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
+        const int n = (int)h[255];
+        fprintf(stderr, "CONV_SK TIMING n=%d:", n);
+        for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+        return true;
+    }
+#endif
+    if (g_prof.on) {
+        ProfEntry e; e.key = upph ? 126 : 125;
+        const double cols = (double)H * W * B * (upph ? 4.0 : 1.0);
+        e.flops = 2.0 * 9 * cin * (double)w.cout * cols;             // reference op count (the parity classes execute 4 / 9 of it)
+        e.bytes = ((double)cin * H * W * 2 + (double)w.cout * cols / B * 2) * B + 9.0 * cin * w.cout * 2;
+        e.dH = H; e.dW = W; e.dCin = cin; e.dCout = w.cout;
+        e.e0 = g_prof.get(); e.e1 = g_prof.get();
+        HIPC(hipEventRecord(e.e0, st));
+        go();
+        HIPC(hipEventRecord(e.e1, st));
+        g_prof.entries.push_back(e);
+    } else go();
+    HIPC(hipGetLastError());
+    return true;
 }
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
@@ -449,6 +548,7 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (want_stats) {
         p.stats_out = y.stats;
     }
+    if (halo && !nchw_out && try_conv_sk(w, x0, x1, y, upph, act, res, want_stats, st)) return false;    // (a res_conv is then a launch of its own)
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
     if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
@@ -1174,7 +1274,7 @@ struct ActPlanner {
 
 static void plan_shapes(ucdir_ctx* c, int B, int H, int W, int pad_mode) {
     c->apool.release();
-    if (!c->splitk) HIPC(hipMalloc((void**)&c->splitk, (size_t)SPLITK_MAX_WGS * 256 * 128 * sizeof(float)));   // (planning never runs under a stream capture)
+    if (!c->splitk) HIPC(hipMalloc((void**)&c->splitk, SCRATCH_BYTES));   // (planning never runs under a stream capture)
     c->rt.assign(c->layers.size(), LayerRT());
     c->B = B; c->H = H; c->W = W; c->pad_mode = pad_mode;
     if (pad_mode) { c->Hc = (H / 32 + 1) * 32; c->Wc = (W / 32 + 1) * 32; require(H >= 33 && W >= 33, "H, W must be >= 33 (reflect pad)"); }
@@ -1531,6 +1631,7 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
     else if (!strcmp(name, "wsb")) g_wsb = value;
+    else if (!strcmp(name, "convsk")) g_convsk = value;       // stream-K conv: 1 forced at any size, 0 off, -1 environment + work threshold
     else if (!strcmp(name, "persist_grid")) g_persist_grid = value;   // persistent kernels: workgroups per launch (0 = one per CU)
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
     API_END

@@ -247,6 +247,32 @@ static inline std::vector<bf16_t> pack_conv_tiled(const PackedConv& P, int TM) {
     return img;
 }
 
+// conv_sk_kernel<MW, NTAPS> (conv_sk.hip.h): every K sub-step's weights as they sit in LDS,
+// [parity class][row tile of 128 MW][32-channel chunk c][tap t][fragment f (4 MW)][k16 j (2)][lane 64][8] bf16: lane (hh = lane >> 5,
+// rho = lane & 31) of fragment f holds W[row][t * cin + 32 c + 16 j + 8 hh .. + 7] with row = 32 f + 16 ((rho >> 2) & 1) + (rho & 3) +
+// 4 (rho >> 3): in the 32 x 32 accumulator layout register r of lane half hh is then channel 32 f + 16 hh + r (16 consecutive channels
+// per lane).  A stage (one tap x 32 channels x all rows of the tile) is 8 MW KB of contiguous memory, fragment reads are lane-linear.
+// A: [npar][rows_pad][Kld] with k = tap * cin + c (pack_conv / pack_upconv images); rows beyond rows_pad are zero.
+static inline std::vector<bf16_t> pack_conv_sk(const std::vector<bf16_t>& A, int npar, int rows_pad, int Kld, int cin, int ntaps, int MW) {
+    const int ROWS = 128 * MW, nrt = (rows_pad + ROWS - 1) / ROWS, nch = cin / 32, nf = 4 * MW;
+    std::vector<bf16_t> img((size_t)npar * nrt * nch * ntaps * nf * 2 * 512, 0);
+    for (int par = 0; par < npar; ++par)
+        for (int rt = 0; rt < nrt; ++rt)
+            for (int c = 0; c < nch; ++c)
+                for (int t = 0; t < ntaps; ++t)
+                    for (int f = 0; f < nf; ++f)
+                        for (int j = 0; j < 2; ++j)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int rho = lane & 31, hh = lane >> 5;
+                                const int row = rt * ROWS + 32 * f + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+                                if (row >= rows_pad) continue;
+                                const bf16_t* src = &A[((size_t)par * rows_pad + row) * Kld + (size_t)t * cin + 32 * c + 16 * j + 8 * hh];
+                                bf16_t* dst = &img[(((((((size_t)par * nrt + rt) * nch + c) * ntaps + t) * nf + f) * 2 + j) * 64 + lane) * 8];
+                                for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                            }
+    return img;
+}
+
 // A fragments of akgm_ws32_kernel<CG> (akgm_ws32.hip.h): [32-feature block C/32][wave 8][k step j NK][lane half hh][32 rows][8] bf16.
 // Wave w of block blk owns features c = 32 blk + 4 w + c4; MFMA row rho <-> (c4 = 2 ((rho >> 2) & 1) + (rho >> 4), sample s = 4 ((rho >> 3) & 1)
 // + (rho & 3)): a lane's 16 accumulators (rows 8 a + 4 hh + i) are then the 8 samples of features 2 hh and 2 hh + 1.  k step j, lane half hk:
