@@ -18,9 +18,13 @@ SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn
 SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, attn_res=(16,), image_size=128)
 
 OP_TOL = 4e-3        # single operator, bf16-representable inputs
-FWD_TOL = 1.5e-2     # full forward (61 GroupNorms deep, bf16 operands AND bf16-stored activations): measured 1.1e-2 on the
-                     # full SID configuration, 1.0-1.3e-2 on the small one; SURVEY.md §8c proposed 1e-2 for bf16 operands
-                     # with fp32 activations - storing activations in bf16 is what the extra 0.1-0.3e-2 buys back in HBM traffic
+FWD_TOL = 1.7e-2     # full forward (61 GroupNorms deep, bf16 operands AND bf16-stored activations).  A torch emulation of the numerics plan
+                     # (bf16 rounding exactly where the kernels round) predicts 1.44e-2 for the full SID configuration; measured over the
+                     # samples / noise levels the tests use: 1.0-1.3e-2 (small configuration), 1.43-1.51e-2 (full SID: seeds 21, 22, 31, 77
+                     # at levels 0.003 ... 0.95).  The spread between samples (+-3 %) is the sampling noise of an rms over a random-weight
+                     # network's rounding errors, so the bound sits 12 % above the largest value seen instead of the 2 % of rounds 1-3
+                     # (round-3 verdict).  SURVEY.md §8c proposed 1e-2 for bf16 operands with fp32 activations; storing activations in
+                     # bf16 is what the extra 0.4e-2 buys back in HBM traffic
 CROP_TOL = 2.0e-2    # a 3 x 32 x 32 crop of the same forward against the REFERENCE's own output: 3,072 values instead of
                      # 196,608, the estimate of the same error is noisier
 
@@ -98,9 +102,14 @@ def test_conv_persistent(args):
     (2, 36, 36, 256, 0, 512, 0, True, True, True, 7),       # residual; 7 workgroups: units cut into three parts (finish kernel sums in workgroup order)
     (2, 16, 24, 128, 0, 256, 2, False, False, False, 0),    # Upsample: four parity classes of 2 x 2 taps
     (3, 9, 9, 256, 0, 512, 2, False, False, False, 5),      # Upsample, stream-K across parity classes and row tiles
-    (1, 72, 72, 96, 32, 256, 0, True, True, False, 0),      # chunk count 4 with the concatenation boundary inside (c0 = 96 = 3 chunks)
+    (1, 72, 72, 192, 64, 256, 0, True, True, False, 0),     # the concatenation boundary inside the chunk sequence (c0 = 192 = 6 chunks of 8)
     (16, 18, 18, 512, 0, 512, 0, True, True, False, 0),     # the 18^2 level of the bench configuration
-], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16"])
+    (2, 24, 40, 64, 64, 128, 0, True, True, False, 0),      # C_out = 128: 128-row x 512-position units (eight waves along the positions)
+    (3, 20, 28, 128, 0, 128, 0, True, True, True, 3),       # the same with a residual, stream-K over 3 workgroups
+    (2, 16, 24, 128, 0, 128, 2, False, False, False, 0),    # Upsample at C_out = 128 (all halo pieces of a chunk at its first sub-step)
+    (1, 144, 144, 64, 0, 128, 0, True, True, False, 0),     # the widest level this kernel takes in the network (halo of 806 positions)
+], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16",
+        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide"])
 def test_conv_stream_k(args):
     """conv_sk_kernel (persistent stream-K 3x3 conv / Upsample parity classes on 256-row x 256-position linear tiles) + its finish
     kernel against torch through the C ABI: batch-flattened tiles (borders computed and dropped, tiles crossing samples), per-sample

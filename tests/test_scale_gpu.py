@@ -20,7 +20,7 @@ from ucdir_amd.weights import synth_inputs  # noqa: E402
 
 SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn_res=(32,), image_size=128)
 SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, attn_res=(16,), image_size=128)
-FWD_TOL = 1.5e-2
+FWD_TOL = 1.7e-2      # see tests/test_hip_gpu.py
 PATCH_TOL = 2.0e-2     # nine separately normalised 256^2 windows: measured 1.51e-2 (single 256^2 forward: 1.1e-2)
 ATT_TOL = 1.2e-2
 SCHED50 = dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=0.4)

@@ -87,17 +87,21 @@ struct SkSched {
     __host__ __device__ long long start(int g) const { return tc * g / G; }
 };
 
+// LDS reads the compiler does not count (an epilogue that runs while the next segment's LDS-DMAs are in flight must not be made to
+// wait for them: hipcc puts vmcnt(0) in front of every LDS read it knows about while an LDS-DMA is outstanding)
+__device__ __forceinline__ void lds_read8f_asm(f32x2_t& v, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+}
+
 // epilogue of one wave's 128 x 64 tile from its accumulators: GroupNorm fold, activation, residual, statistics, bf16 NHWC store.
-// Shared by the conv kernel and the finish kernel (identical arithmetic: a unit finished in-kernel or from partial tiles gives the
-// same bits for the same accumulator values).
-template <int MW>
-__device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, f32x16_t (&acc)[4][2], int par, int rt, int tile,
-                                            int wm, int wn, int lane) {
+// Shared by the conv kernel (LDS_TAB: fold tables and per-sample scalars in LDS, read by uncounted inline asm) and the finish kernel
+// (tables straight from bias / Tb / Tg in global memory, scalars in its own LDS): identical arithmetic - a unit finished in-kernel
+// or from partial tiles gives the same bits for the same accumulator values.
+template <int MW, bool LDS_TAB>
+__device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[4][2],
+                                            int par, int rt, int tile, int wm, int wn, int lane) {
     using L = CvSk<MW>;
     const int hh = lane >> 5, l31 = lane & 31;
-    const float* tb = reinterpret_cast<const float*>(smem + L::OFF_TB);
-    const float* tg = reinterpret_cast<const float*>(smem + L::OFF_TG);
-    const float* ms = reinterpret_cast<const float*>(smem + L::OFF_MS);
     const int act = p.act;
     const int py = par >> 1, pxp = par & 1;
 #pragma unroll
@@ -107,7 +111,15 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
         const int yp = r / p.Wp, xp = r - yp * p.Wp;
         const bool valid = q < p.npos && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
         const int bb = b < p.nb ? b : p.nb - 1;
-        const float ra = ms[2 * bb], mr = ms[2 * bb + 1];
+        float ra, mr;
+        if (LDS_TAB) {
+            f32x2_t m2;
+            lds_read8f_asm(m2, (unsigned)(L::OFF_MS + 8 * bb));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m2));                             // (the value is only touched behind the wait: cdna guide 5.7 form iii)
+            __builtin_amdgcn_sched_barrier(0);
+            ra = m2[0]; mr = m2[1];
+        } else { ra = ms_plain[2 * bb]; mr = ms_plain[2 * bb + 1]; }
         const int y = yp - 1, x = xp - 1;
         const int cls = p.npar > 1 ? 4 : (y <= 0 ? 0 : (y >= p.H - 1 ? 2 : 1)) * 3 + (x <= 0 ? 0 : (x >= p.W - 1 ? 2 : 1));
         long long opos = q;
@@ -116,14 +128,37 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int ch = wm * 128 + f * 32 + 16 * hh;                // channel within the row tile
+            const int fo = rt * L::ROWS + ch;
+            f32x4_t b4[4], g4v[4];
+            if (LDS_TAB) {
+                const unsigned ta = (unsigned)(L::OFF_TB + (cls * L::ROWS + ch) * 4), ga = ta + (unsigned)(L::OFF_TG - L::OFF_TB);
+                lds_read16f_asm<0>(b4[0], ta); lds_read16f_asm<16>(b4[1], ta); lds_read16f_asm<32>(b4[2], ta); lds_read16f_asm<48>(b4[3], ta);
+                lds_read16f_asm<0>(g4v[0], ga); lds_read16f_asm<16>(g4v[1], ga); lds_read16f_asm<32>(g4v[2], ga); lds_read16f_asm<48>(g4v[3], ga);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(b4[g4]), "+v"(g4v[g4]));
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int fg = fo + 4 * g4;
+                    f32x4_t vb = {0.f, 0.f, 0.f, 0.f}, vg = {0.f, 0.f, 0.f, 0.f};
+                    if (fg < p.nfeat) {
+                        if (p.bias) vb = *reinterpret_cast<const f32x4_t*>(p.bias + fg);
+                        if (p.fold) {
+                            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.Tb + (long long)cls * p.tab_ld + fg);
+                            vb[0] += t[0]; vb[1] += t[1]; vb[2] += t[2]; vb[3] += t[3];
+                            vg = *reinterpret_cast<const f32x4_t*>(p.Tg + (long long)cls * p.tab_ld + fg);
+                        }
+                    }
+                    b4[g4] = vb; g4v[g4] = vg;
+                }
+            }
             float v[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(tb + cls * L::ROWS + ch + 4 * g4);
-                const f32x4_t g4v = *reinterpret_cast<const f32x4_t*>(tg + cls * L::ROWS + ch + 4 * g4);
+            for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g4 + e] = fmaf(acc[f][n][4 * g4 + e], ra, fmaf(-mr, g4v[e], b4[e]));
-            }
+                for (int e = 0; e < 4; ++e) v[4 * g4 + e] = fmaf(acc[f][n][4 * g4 + e], ra, fmaf(-mr, g4v[g4][e], b4[g4][e]));
             if (act == 1) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = silu_fast(v[i]);
@@ -131,7 +166,6 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = fmaxf(0.2f * v[i], v[i]);
             }
-            const int fo = rt * L::ROWS + ch;
             if (valid && fo < p.nfeat) {
                 if (p.res) {
                     const uint4 r0 = *reinterpret_cast<const uint4*>(p.res + opos * p.res_ld + fo);
@@ -161,12 +195,9 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
     }
 }
 
-// per-workgroup tables: (alpha * rstd, mean * rstd) of every sample; then (bias + Tb, Tg) of a row tile
-template <int MW>
-__device__ __forceinline__ void sk_sample_table(const ConvSkP& p, unsigned char* smem, int wave, int lane) {
-    using L = CvSk<MW>;
-    float* ms = reinterpret_cast<float*>(smem + L::OFF_MS);
-    for (int b = wave; b < p.nb; b += 8) {
+// (alpha * rstd, mean * rstd) of samples [b0, b1) into ms[2 (b - b0) ..]; wave `wave` of `nwaves` takes every nwaves-th sample
+__device__ __forceinline__ void sk_sample_table(const ConvSkP& p, float* ms, int b0, int b1, int wave, int nwaves, int lane) {
+    for (int b = b0 + wave; b < b1; b += nwaves) {
         float mean = 0.f, rstd = 1.f;
         if (p.fold) {
             long long v = 0;
@@ -179,9 +210,10 @@ __device__ __forceinline__ void sk_sample_table(const ConvSkP& p, unsigned char*
             const long long q = __shfl(v, 1);
             mean_rstd(stat_val(v), stat_val(q), p.inv_count, mean, rstd);
         }
-        if (lane == 0) { ms[2 * b] = p.alpha * rstd; ms[2 * b + 1] = p.fold ? mean * rstd : 0.f; }
+        if (lane == 0) { ms[2 * (b - b0)] = p.alpha * rstd; ms[2 * (b - b0) + 1] = p.fold ? mean * rstd : 0.f; }
     }
 }
+// (bias + Tb, Tg) of row tile rt, all nine border classes
 template <int MW>
 __device__ __forceinline__ void sk_row_table(const ConvSkP& p, unsigned char* smem, int rt, int tid) {
     using L = CvSk<MW>;
@@ -226,55 +258,13 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
                                                                      // wait covers everything requested up to S(NTAPS - 4)
     constexpr int HPER = (NHW + TA - 1) / TA;                        // pieces per such S point
 
-    sk_sample_table<MW>(p, smem, wave, lane);
-
     // ---- per-lane constants of the fragment reads ------------------------------------------------------------------------
     // A: stage slot s, fragment f (32 rows), k16 j: 1 KB lane-linear at s * STAGE + ((4 wm + f) * 2 + j) * 1024 + lane * 16
     const unsigned a_lane = L::OFF_W + (4 * wm) * 2048 + lane * 16;
     // B: tap t, MFMA tile n: halo position hp = 64 wn + 32 n + l31 + ky Wp + kx; 64 bytes per position, 16-byte chunk
-    // (2 jj + hh) ^ ((hp >> 2) & 3): address(jj = 1) = address(jj = 0) ^ 32
+    // (2 jj + hh) ^ ((hp >> 2) & 3): address(jj = 1) = address(jj = 0) ^ 32.  (Upsample parity classes: per segment.)
     unsigned bx[NTAPS][2];
-    const int par_of = 0;
-    (void)par_of;
-
-    // ---- halo staging geometry: piece i = 16 positions; lane -> (position 16 i + lane / 4, physical chunk lane & 3) -----------
-    // (source offsets are per tile; see tile_setup)
-    const SkSched sch(p.units, p.ndp, nch, G);
-    const long long c_beg = sch.start(lid), c_end = sch.start(lid + 1);      // stream-K chunk range of this workgroup
-    const int ndp_mine = lid < p.ndp ? (p.ndp - lid + G - 1) / G : 0;        // whole units g, g + G, ...
-
-    int rt_cur = -1;
-    int seg = 0;                                                             // segment counter (partial-slot choice)
-    long long cpos = c_beg;
-    int dpi = 0;
-#pragma unroll 1
-    while (true) {
-        // ---- next segment: (unit, chunk range) ----------------------------------------------------------------------------
-        int unit, cb, ce;
-        bool first_sk = false;
-        if (dpi < ndp_mine) { unit = lid + dpi * G; cb = 0; ce = nch; ++dpi; }
-        else if (cpos < c_end) {
-            const long long u = cpos / nch;
-            unit = p.ndp + (int)u; cb = (int)(cpos - u * nch);
-            const long long e = (u + 1) * nch < c_end ? (u + 1) * nch : c_end;
-            ce = (int)(e - u * nch);
-            first_sk = cpos == c_beg;
-            cpos = e;
-        } else break;
-        const bool whole = cb == 0 && ce == nch;
-        int par = 0, rt, tile;
-        {
-            int u = unit;
-            const int per_par = p.rowtiles * p.ntiles;
-            if (p.npar > 1) { par = u / per_par; u -= par * per_par; }
-            rt = u / p.ntiles; tile = u - rt * p.ntiles;
-        }
-        const int py = par >> 1, pxp = par & 1;
-        __syncthreads();                                             // everybody is done with the previous segment's LDS (tables, ring, halo)
-        if (rt != rt_cur) { sk_row_table<MW>(p, smem, rt, tid); rt_cur = rt; }
-
-        // ---- tile geometry -------------------------------------------------------------------------------------------------
-        const int q0 = tile * L::NPX;
+    auto set_bx = [&](int py, int pxp) {
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             int ky, kx;
@@ -285,36 +275,88 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
                 bx[t][n] = L::OFF_H + (hp << 6) + (((hh ^ (hp >> 2)) & 3) << 4);
             }
         }
-        // halo pieces of this wave: j-th piece = piece j * 8 + wave (clamped: a repeat of the last piece is harmless)
-        unsigned hq[NHW], hsw[NHW]; int hdst[NHW];
+    };
+    if (NTAPS == 9) set_bx(0, 0);
+    // halo staging: piece i = 16 positions; lane -> (position 16 i + lane / 4, physical 16-byte chunk lane & 3 = logical ^ ((pos >> 2) & 3));
+    // this wave's j-th piece is piece j * 8 + wave (past the halo's end: a repeat of its last piece)
+    int hpos[NHW], hdst[NHW]; unsigned hsw[NHW];
+#pragma unroll
+    for (int j = 0; j < NHW; ++j) {
+        int i = j * 8 + wave; i = i < nhp ? i : nhp - 1;
+        hpos[j] = 16 * i + (lane >> 2) - Wp - 1;                     // + q0: position in the tensor
+        hsw[j] = (unsigned)(((lane & 3) ^ (((16 * i + (lane >> 2)) >> 2) & 3)) << 3);
+        hdst[j] = L::OFF_H + i * 1024;
+    }
+
+    const SkSched sch(p.units, p.ndp, nch, G);
+    const long long c_beg = sch.start(lid), c_end = sch.start(lid + 1);      // stream-K chunk range of this workgroup
+    const int ndp_mine = lid < p.ndp ? (p.ndp - lid + G - 1) / G : 0;        // whole units lid, lid + G, ...
+    long long cpos = c_beg;
+    int dpi = 0;
+    struct Seg { int unit, cb, ce, par, rt, tile; bool first_sk, ok; };
+    auto next_segment = [&]() {
+        Seg s; s.ok = true; s.first_sk = false;
+        if (dpi < ndp_mine) { s.unit = lid + dpi * G; s.cb = 0; s.ce = nch; ++dpi; }
+        else if (cpos < c_end) {
+            const long long u = cpos / nch;
+            s.unit = p.ndp + (int)u; s.cb = (int)(cpos - u * nch);
+            const long long e = (u + 1) * nch < c_end ? (u + 1) * nch : c_end;
+            s.ce = (int)(e - u * nch);
+            s.first_sk = cpos == c_beg;
+            cpos = e;
+        } else { s.ok = false; s.unit = 0; s.cb = 0; s.ce = 0; }
+        int u = s.unit;
+        const int per_par = p.rowtiles * p.ntiles;
+        s.par = 0;
+        if (p.npar > 1) { s.par = u / per_par; u -= s.par * per_par; }
+        s.rt = u / p.ntiles; s.tile = u - s.rt * p.ntiles;
+        return s;
+    };
+
+    // per-segment state of the DMA streams
+    unsigned hq[NHW];                                                // clamped tensor positions of this wave's halo pieces
+    const bf16_t* a_seg = nullptr;                                   // this lane's source of stage 0 of the segment (+ k * STAGE / 2)
+    int seg_cb = 0;
+    auto issue_halo = [&](int c, int j, int buf) {                   // piece j of chunk c into halo buffer buf
+        int ch = c * 32;
+        const bf16_t* src; int ld;
+        if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
+        const unsigned off = hq[j] * (unsigned)ld + hsw[j] + (unsigned)ch;
+        stage16(src + off, smem + hdst[j] + buf * HB, lane);
+    };
+    auto issue_stage = [&](int k, int slot) {                        // stage k of the segment's (parity, row tile); past its end: whatever follows
+#pragma unroll                                                       // in the image (the image is padded by four stages) into a slot nobody reads any more
+        for (int j = 0; j < L::PW; ++j)
+            stage16(a_seg + (long long)k * (L::STAGE / 2) + j * 512, smem + L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024, lane);
+    };
+    auto prefetch = [&](const Seg& s) {                              // halo of the first chunk and stages 0 .. 3 of segment s
+        if (NTAPS != 9) set_bx(s.par >> 1, s.par & 1);
+        const int q0 = s.tile * L::NPX;
 #pragma unroll
         for (int j = 0; j < NHW; ++j) {
-            int i = j * 8 + wave; i = i < nhp ? i : nhp - 1;
-            const int pos = 16 * i + (lane >> 2);
-            int q = q0 - Wp - 1 + pos;
+            int q = q0 + hpos[j];
             q = q < 0 ? 0 : (q >= p.npos ? p.npos - 1 : q);
-            hq[j] = (unsigned)q; hsw[j] = (unsigned)(((lane & 3) ^ ((pos >> 2) & 3)) << 3);
-            hdst[j] = i * 1024;
+            hq[j] = (unsigned)q;
         }
-        auto issue_halo = [&](int c, int j, bool real) {         // piece j of chunk c into buffer (c - cb) & 1
-            int ch = c * 32;
-            const bf16_t* src; int ld;
-            if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
-            const unsigned off = hq[j] * (unsigned)ld + hsw[j] + (unsigned)ch;
-            unsigned char* dst = real ? smem + L::OFF_H + ((c - cb) & 1) * HB + hdst[j] : smem + L::OFF_DUMMY;
-            stage16(src + off, dst, lane);
-        };
-        // weights: stage k of this (parity, row tile) at A + ((par * rowtiles + rt) * nch * NTAPS + k) * STAGE / 2 elements
-        const bf16_t* const a_tile = p.A + (long long)par * p.a_par_stride + ((long long)rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512 + lane * 8;
-        const int k_end = ce * NTAPS;
-        auto issue_stage = [&](int k, int slot) {
-            const bool real = k < k_end;
-            const bf16_t* src = a_tile + (long long)(real ? k : k_end - 1) * (L::STAGE / 2);
+        a_seg = p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512 + lane * 8;
+        seg_cb = s.cb;
 #pragma unroll
-            for (int j = 0; j < L::PW; ++j)
-                stage16(src + j * 512, real ? smem + L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024 : smem + L::OFF_DUMMY, lane);
-        };
+        for (int j = 0; j < NHW; ++j) issue_halo(s.cb, j, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) issue_stage(s.cb * NTAPS + k, k);
+    };
 
+    sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS), 0, p.nb, wave, 8, lane);
+    Seg cur = next_segment();
+    if (!cur.ok) return;
+    int rt_cur = cur.rt;
+    sk_row_table<MW>(p, smem, cur.rt, tid);
+    prefetch(cur);
+
+#pragma unroll 1
+    while (true) {
+        const Seg nxt = next_segment();
+        const int cb = cur.cb, ce = cur.ce;
         f32x16_t acc[4][2];
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -323,21 +365,13 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[f][n][e] = 0.f;
 
-        // ---- prologue: halo of chunk cb, stages 0 .. 3 --------------------------------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < NHW; ++j) issue_halo(cb, j, true);
-        {
-            const int k0 = cb * NTAPS;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) issue_stage(k0 + s, s);
-        }
-        HC_WAIT(0);
+        HC_WAIT(0);                                                  // this segment's first halo and stages 0 .. 3 (requested under the previous epilogue)
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         SK_STAMP();
 
         bf16x8_t fa[2][4], fb[2][2];
-        // R(t, jj) of sub-step h: A from slot h & 3, B from the halo buffer of its chunk (bx[][] is kept at the CURRENT chunk's buffer)
+        // R(t, jj) of sub-step h: A from slot h & 3, B from the halo buffer of its chunk
         auto reads = [&](auto tc, auto jc, int h, unsigned boff) {
             constexpr int t = decltype(tc)::value, jj = decltype(jc)::value;
             const unsigned aa = a_lane + (unsigned)((h & 3) * L::STAGE);
@@ -350,8 +384,6 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
             lds_read16_asm<0>(fb[jj][1], b1);
         };
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // nothing of the compiler's own is in the LDS / scalar queue from here on
-        __builtin_amdgcn_sched_barrier(0);
         reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, 0u);
         reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, 0u);
 
@@ -360,6 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
 #pragma unroll 1
         for (int c = cb; c < ce; ++c) {
             const unsigned bnext = bcur ? 0u : (unsigned)HB;
+            const int cn = c + 1 < ce ? c + 1 : c;                   // (behind the last chunk: its own halo again, into the OTHER buffer, which nobody reads any more)
             static_for<0, NTAPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int tn = (t + 1) % NTAPS;
@@ -382,8 +415,7 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
                     asm volatile("s_barrier" ::: "memory");
                     if constexpr (t < TA) {
                         constexpr int j0 = t * HPER < NHW ? t * HPER : NHW, j1 = (t + 1) * HPER < NHW ? (t + 1) * HPER : NHW;
-                        const bool more = c + 1 < ce;
-                        static_for<j0, j1>([&](auto jc) { issue_halo(more ? c + 1 : c, decltype(jc)::value, more); });
+                        static_for<j0, j1>([&](auto jc) { issue_halo(cn, decltype(jc)::value, bnext ? 1 : 0); });
                     }
                     issue_stage(cb * NTAPS + h + 4, h & 3);
                 }
@@ -397,6 +429,8 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
             });
             bcur = bnext;
         }
+        // drain: the reads past the segment's end (garbage, never used) and the DMAs past its end must be gone before the buffers are
+        // refilled; the barrier makes that true for every wave's reads
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -405,13 +439,18 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
             asm volatile("" : "+v"(fb[jj][0]), "+v"(fb[jj][1]));
         }
         __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
         SK_STAMP();
+        // the next segment's first halo and stages fly under this segment's epilogue (same row tile: its LDS reads are uncounted inline asm)
+        const bool same_rt = nxt.ok && nxt.rt == rt_cur;
+        if (same_rt) prefetch(nxt);
+        __builtin_amdgcn_sched_barrier(0);
 
-        if (whole) {
-            sk_epilogue<MW>(p, smem, acc, par, rt, tile, wm, wn, lane);
+        if (cb == 0 && ce == nch) {
+            sk_epilogue<MW, true>(p, smem, nullptr, acc, cur.par, cur.rt, cur.tile, wm, wn, lane);
         } else {
             // raw accumulators, accumulator layout: [wave][f][n][reg / 4][lane][4] fp32 - coalesced 16-byte stores
-            float* pw = p.partial + ((long long)(2 * lid + (first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
+            float* pw = p.partial + ((long long)(2 * lid + (cur.first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -422,41 +461,42 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
                             make_float4(acc[f][n][4 * g4], acc[f][n][4 * g4 + 1], acc[f][n][4 * g4 + 2], acc[f][n][4 * g4 + 3]);
         }
         SK_STAMP();
-        ++seg;
+        if (!nxt.ok) break;
+        if (!same_rt) {                                              // another row tile: its fold tables replace the current ones behind the epilogue
+            __syncthreads();
+            sk_row_table<MW>(p, smem, nxt.rt, tid);
+            rt_cur = nxt.rt;
+            prefetch(nxt);
+        }
+        cur = nxt;
     }
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[255] = dbg_n;
 #endif
 }
 
-// Second half of a stream-K launch: one workgroup per cut unit sums the partial tiles in ascending workgroup order and runs the
-// epilogue.  grid = number of stream-K units; units that one workgroup computed whole exit at once.
+// Second half of a stream-K launch: sums the partial tiles of every cut unit in ascending workgroup order (fixed: bit-reproducible)
+// and runs the epilogue.  grid = (8, stream-K units): one WAVE per workgroup, the slice of the unit that wave `blockIdx.x` of the conv
+// kernel owns (688 small workgroups instead of 86 large ones: the pass is bound by reading ~1 MB per unit); units that one
+// workgroup computed whole exit at once.
 template <int MW>
-__global__ __launch_bounds__(512, 2) void conv_sk_finish_kernel(const ConvSkP p, int G) {
+__global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int G) {
     using L = CvSk<MW>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float ms[2 * L::MAXB];
     constexpr int NWN = 8 / MW;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x;
+    const int wave = blockIdx.x;
     const int wm = wave / NWN, wn = wave % NWN;
     const int nch = p.nchunks;
     const SkSched sch(p.units, p.ndp, nch, G);
-    const int u = blockIdx.x;                                        // stream-K unit index
+    const int u = blockIdx.y;                                        // stream-K unit index
     const long long a = (long long)u * nch, b = a + nch;             // its chunk range
     // workgroups whose range meets [a, b): the first is the one that holds chunk a
-    int g = (int)((a * G + G - 1) / sch.tc);                         // smallest g with start(g + 1) > a: search around the estimate
+    int g = (int)(a * G / sch.tc);
     if (g >= G) g = G - 1;
     while (g > 0 && sch.start(g) > a) --g;
     while (sch.start(g + 1) <= a) ++g;
     if (sch.start(g) <= a && sch.start(g + 1) >= b) return;          // computed whole by one workgroup
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[f][n][e] = 0.f;
-    sk_sample_table<MW>(p, smem, wave, lane);
     int par = 0, rt, tile;
     {
         int uu = p.ndp + u;
@@ -464,9 +504,10 @@ __global__ __launch_bounds__(512, 2) void conv_sk_finish_kernel(const ConvSkP p,
         if (p.npar > 1) { par = uu / per_par; uu -= par * per_par; }
         rt = uu / p.ntiles; tile = uu - rt * p.ntiles;
     }
-    sk_row_table<MW>(p, smem, rt, tid);
+    sk_sample_table(p, ms, 0, p.nb, 0, 1, lane);                     // (a few samples; the loads of the first partial tile fly meanwhile)
+    f32x16_t acc[4][2];
+    bool have = false;
     for (; g < G && sch.start(g) < b; ++g) {
-        if (sch.start(g + 1) <= a) continue;
         const bool first = sch.start(g) >= a;                        // this unit holds the workgroup's first chunk: its first segment
         const float* pr = p.partial + ((long long)(2 * g + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
 #pragma unroll
@@ -476,9 +517,11 @@ __global__ __launch_bounds__(512, 2) void conv_sk_finish_kernel(const ConvSkP p,
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const float4 v = *reinterpret_cast<const float4*>(pr + ((f * 2 + n) * 4 + g4) * 256);
-                    acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w;
+                    if (have) { acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w; }
+                    else { acc[f][n][4 * g4] = v.x; acc[f][n][4 * g4 + 1] = v.y; acc[f][n][4 * g4 + 2] = v.z; acc[f][n][4 * g4 + 3] = v.w; }
                 }
+        have = true;
     }
     __syncthreads();
-    sk_epilogue<MW>(p, smem, acc, par, rt, tile, wm, wn, lane);
+    sk_epilogue<MW, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane);
 }

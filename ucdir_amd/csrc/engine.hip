@@ -128,17 +128,20 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     W.rows_pad = P.rows_pad; W.Kpad = P.Kpad; W.ntaps = P.ntaps; W.cin = cin; W.cout = cout;
     if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
     if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && P.rows_pad % W.TM == 0) W.Atile = pool.upload(pack_conv_tiled(P, W.TM));
-    if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && cout % 256 == 0) { W.sk_mw = 2; W.Ask = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 2)); }
+    if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && cout % 128 == 0) {
+        W.sk_mw = cout % 256 == 0 ? 2 : 1;                // 256-row x 256-position units, or 128 x 512 (C_out = 128, 384)
+        W.Ask = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, W.sk_mw));
+    }
     if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
 }
 static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
     PackedConv P = pack_upconv(w, bias, W.cout, W.cin, W.TM);
     W.Aup = pool.upload(P.A); W.Kup = P.Kpad;
-    if (W.cin % 32 == 0 && W.cout % 256 == 0) {
-        W.sk_mw = 2;
-        std::vector<bf16_t> img = pack_conv_sk(P.A, 4, P.rows_pad, P.Kpad, W.cin, 4, 2);
-        W.sk_up_stride = (long long)(img.size() / 4);
+    if (W.cin % 32 == 0 && W.cout % 128 == 0) {
+        W.sk_mw = W.cout % 256 == 0 ? 2 : 1;
+        std::vector<bf16_t> img = pack_conv_sk(P.A, 4, P.rows_pad, P.Kpad, W.cin, 4, W.sk_mw);
+        W.sk_up_stride = (long long)((img.size() - (size_t)4 * 4 * W.sk_mw * 2 * 512) / 4);   // (the image ends in four stages of padding)
         W.Ask_up = pool.upload(img);
     }
 }
@@ -207,7 +210,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
     set_lds_attr(conv_sk_kernel<2, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 4>, 160 * 1024);
-    set_lds_attr(conv_sk_finish_kernel<2>, CvSk<2>::lds_bytes(0));
+    set_lds_attr(conv_sk_kernel<1, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<1, 4>, 160 * 1024);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -417,31 +420,25 @@ static int choose_usplit(int nblk) {
 
 // ---- conv_sk_kernel (conv_sk.hip.h): persistent stream-K 3x3 conv / Upsample parity classes on 256-row tiles -------------------------
 static std::atomic<int> g_convsk{-1};          // -1: environment (UCDIR_NO_CONV_SK) + work threshold, 0: off, 1: forced (tests: any size)
-static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st) {
-    static const bool env_on = !getenv("UCDIR_NO_CONV_SK");
-    const int mode = g_convsk.load();
-    if (mode == 0 || (mode < 0 && !env_on)) return false;
+template <int MW>
+static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, int mode) {
+    using L = CvSk<MW>;
     const bf16_t* img = upph ? w.Ask_up : w.Ask;
-    if (!img || w.sk_mw != 2) return false;
     const int cin = x0.C + (x1 ? x1->C : 0);
-    if (x0.C % 32 || (x1 && x1->C % 32) || y.C % 8) return false;
     const int H = x0.H, W = x0.W, Wp = W + 2, HpWp = (H + 2) * Wp, B = x0.B;
-    if (B > CvSk<2>::MAXB) return false;
+    if (B > L::MAXB) return false;
     const long long npos = (long long)B * HpWp;
     if (npos * (long long)(cin > y.C ? cin : y.C) * (upph ? 4 : 1) >= (1LL << 31)) return false;      // 32-bit element offsets in the kernel
-    const int NPX = CvSk<2>::NPX;
+    const int NPX = L::NPX;
     const int nhp = (NPX + 2 * Wp + 2 + 15) / 16;
-    if (CvSk<2>::lds_bytes(nhp) > 160 * 1024) return false;
-    const int ntaps = upph ? 4 : 9;
-    (void)ntaps;
-    if (nhp > CvSk<2>::NHP_MAX) return false;                                                        // fixed halo piece count per wave
+    if (L::lds_bytes(nhp) > 160 * 1024 || nhp > L::NHP_MAX) return false;                            // halo buffers; fixed halo piece count per wave
     ConvSkP p; std::memset(&p, 0, sizeof(p));
     p.A = img; p.a_par_stride = upph ? w.sk_up_stride : 0;
     p.B0 = x0.p; p.ld0 = x0.C; p.c0 = x0.C;
     if (x1) { p.B1 = x1->p; p.ld1 = x1->C; }
     p.nchunks = cin / 32;
     p.nb = B; p.H = H; p.W = W; p.Wp = Wp; p.HpWp = HpWp; p.npos = (int)npos;
-    p.ntiles = (int)((npos + NPX - 1) / NPX); p.rowtiles = (w.cout + 255) / 256; p.npar = upph ? 4 : 1;
+    p.ntiles = (int)((npos + NPX - 1) / NPX); p.rowtiles = (w.cout + L::ROWS - 1) / L::ROWS; p.npar = upph ? 4 : 1;
     p.nhp = nhp; p.nfeat = w.cout;
     p.alpha = 1.f; p.fold = (!upph && w.fold) ? 1 : 0; p.act = act;
     if (p.fold) {
@@ -457,15 +454,15 @@ static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bo
     int G = num_cus(); if (G > SK_MAX_GRID) G = SK_MAX_GRID;
     const long long work = (long long)p.units * p.nchunks;           // chunks of 9 (4) sub-steps
     if (mode < 0 && (work < 3LL * G || p.units * 8 < G)) return false;   // too little for one workgroup per CU: the one-shot kernels (split-K) are faster
-    if (G > p.units * p.nchunks) G = (int)(p.units * p.nchunks);
+    if (G > work) G = (int)work;
     p.ndp = (p.units / G) * G;
     p.partial = splitk_scratch();
-    const size_t lds = CvSk<2>::lds_bytes(nhp);
+    const size_t lds = L::lds_bytes(nhp);
     const int nsk = p.units - p.ndp;
     auto go = [&]() {
-        if (upph) hipLaunchKernelGGL((conv_sk_kernel<2, 4>), dim3(G), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_sk_kernel<2, 9>), dim3(G), dim3(512), lds, st, p);
-        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<2>), dim3(nsk), dim3(512), CvSk<2>::lds_bytes(0), st, p, G);
+        if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, 4>), dim3(G), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_sk_kernel<MW, 9>), dim3(G), dim3(512), lds, st, p);
+        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW>), dim3(8, nsk), dim3(64), 0, st, p, G);
     };
 #ifdef UCDIR_TIMING
     {
@@ -498,6 +495,16 @@ static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bo
     } else go();
     HIPC(hipGetLastError());
     return true;
+}
+static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st) {
+    static const bool env_on = !getenv("UCDIR_NO_CONV_SK");
+    const int mode = g_convsk.load();
+    if (mode == 0 || (mode < 0 && !env_on)) return false;
+    if (!(upph ? w.Ask_up : w.Ask)) return false;
+    if (x0.C % 32 || (x1 && x1->C % 32) || y.C % 8) return false;
+    if (w.sk_mw == 2) return try_conv_sk_mw<2>(w, x0, x1, y, upph, act, res, want_stats, st, mode);
+    if (w.sk_mw == 1) return try_conv_sk_mw<1>(w, x0, x1, y, upph, act, res, want_stats, st, mode);
+    return false;
 }
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation

@@ -255,7 +255,8 @@ static inline std::vector<bf16_t> pack_conv_tiled(const PackedConv& P, int TM) {
 // A: [npar][rows_pad][Kld] with k = tap * cin + c (pack_conv / pack_upconv images); rows beyond rows_pad are zero.
 static inline std::vector<bf16_t> pack_conv_sk(const std::vector<bf16_t>& A, int npar, int rows_pad, int Kld, int cin, int ntaps, int MW) {
     const int ROWS = 128 * MW, nrt = (rows_pad + ROWS - 1) / ROWS, nch = cin / 32, nf = 4 * MW;
-    std::vector<bf16_t> img((size_t)npar * nrt * nch * ntaps * nf * 2 * 512, 0);
+    // (+ four stages of zeros: the kernel's weight ring requests up to four stages past the end of a row tile's sequence)
+    std::vector<bf16_t> img((size_t)npar * nrt * nch * ntaps * nf * 2 * 512 + (size_t)4 * nf * 2 * 512, 0);
     for (int par = 0; par < npar; ++par)
         for (int rt = 0; rt < nrt; ++rt)
             for (int c = 0; c < nch; ++c)
