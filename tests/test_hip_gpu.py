@@ -107,16 +107,21 @@ def test_conv_persistent(args):
     (2, 24, 40, 64, 64, 128, 0, True, True, False, 0),      # C_out = 128: 128-row x 512-position units (eight waves along the positions)
     (3, 20, 28, 128, 0, 128, 0, True, True, True, 3),       # the same with a residual, stream-K over 3 workgroups
     (2, 16, 24, 128, 0, 128, 2, False, False, False, 0),    # Upsample at C_out = 128 (all halo pieces of a chunk at its first sub-step)
-    (1, 144, 144, 64, 0, 128, 0, True, True, False, 0),     # the widest level this kernel takes in the network (halo of 806 positions)
+    (1, 144, 144, 64, 0, 128, 0, True, True, False, 0),     # the widest level this kernel takes in the network (halo of 806 positions; three strips of 48 for the 4-wave kind)
+    (2, 50, 70, 64, 0, 128, 0, True, True, False, 0),       # two strips of 35 columns (4-wave kind), ragged in every direction
+    (1, 40, 100, 64, 0, 256, 2, False, False, False, 0),    # Upsample on strips
 ], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16",
-        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide"])
-def test_conv_stream_k(args):
+        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide", "strips_ragged", "strips_up"])
+@pytest.mark.parametrize("kind", [1, 2], ids=["persistent8", "oneshot4"])
+def test_conv_stream_k(args, kind):
     """conv_sk_kernel (persistent stream-K 3x3 conv / Upsample parity classes on 256-row x 256-position linear tiles) + its finish
     kernel against torch through the C ABI: batch-flattened tiles (borders computed and dropped, tiles crossing samples), per-sample
-    GroupNorm fold in the epilogue, fixed-order partial sums, statistics."""
+    GroupNorm fold in the epilogue, fixed-order partial sums, statistics.  kind 1: one persistent 8-wave workgroup per CU (256 x 256 or
+    128 x 512 units, stream-K remainder); kind 2: 4-wave workgroups of 128 x 256, two per CU, one unit each (with a forced grid:
+    ranges of units and a stream-K remainder too); both on vertical strips where the image is too wide for the halo buffers."""
     B, H, W, c0, c1, cout, mode, gn, silu, residual, grid = args
     L = C.ulib.load()
-    C.ulib.check(L.ucdir_debug_flag(b"convsk", 1))
+    C.ulib.check(L.ucdir_debug_flag(b"convsk", kind))
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
     try:
         (m, keys) = _profile_keys(L, lambda: C.conv_case(B, H, W, c0, c1, cout, 3, mode, gn, silu, residual, seed=5))
@@ -124,7 +129,7 @@ def test_conv_stream_k(args):
     finally:
         C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
         C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
-    assert (126 if mode == 2 else 125) in keys, keys                # the stream-K kernel ran, not a fallback
+    assert (125 if kind == 1 else 127) + (1 if mode == 2 else 0) in keys, keys      # the new kernel ran, not a fallback
     assert not m["nan"] and m["rel_rms"] < OP_TOL, m
     assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0), m
     assert m["stats_rel"] < 1e-3, m

@@ -45,7 +45,7 @@ for (H, c0, c1, cout, mode) in SHAPES:
     Ho = 2 * H if mode == 2 else H
     y = torch.empty(B, cout, Ho, Ho, device="cuda")
     out = []
-    for sk in (0, 1):
+    for sk in (0, 1, 2):
         ulib.check(L.ucdir_debug_flag(b"convsk", sk))
         best = None
         for r in range(reps + 1):
@@ -54,13 +54,14 @@ for (H, c0, c1, cout, mode) in SHAPES:
                                        C._p(None), C._p(y), C._hp(None), C._st()))
             ulib.check(L.ucdir_profile_enable(0))
             if r:
-                rows = [x for x in prof_read() if x[0] in (20, 21, 22, 120, 121, 125, 126)]
+                rows = [x for x in prof_read() if x[0] in (20, 21, 22, 120, 121, 125, 126, 127, 128)]
                 t = sum(x[2] for x in rows)
                 best = t if best is None or t < best else best
                 key = rows[0][0] if rows else -1
         flops = 2.0 * 9 * cin * cout * Ho * Ho * B
         out.append((key, best, flops / (best * 1e-3) / 1e12 if best else 0.0, float(y.abs().mean())))
     ulib.check(L.ucdir_debug_flag(b"convsk", -1))
-    print("%-28s one-shot key %3d %8.1f us %7.1f TF | stream-K key %3d %8.1f us %7.1f TF | x%.2f  (mean |y| %.4f / %.4f)" % (
-        tag, out[0][0], out[0][1] * 1e3, out[0][2], out[1][0], out[1][1] * 1e3, out[1][2], out[0][1] / max(out[1][1], 1e-9), out[0][3], out[1][3]))
+    print("%-26s old %3d %7.1f us %6.1f TF | persistent8 %3d %7.1f us %6.1f TF x%.2f | oneshot4 %3d %7.1f us %6.1f TF x%.2f  (|y| %.4f %.4f %.4f)" % (
+        tag, out[0][0], out[0][1] * 1e3, out[0][2], out[1][0], out[1][1] * 1e3, out[1][2], out[0][1] / max(out[1][1], 1e-9),
+        out[2][0], out[2][1] * 1e3, out[2][2], out[0][1] / max(out[2][1], 1e-9), out[0][3], out[1][3], out[2][3]))
     sys.stdout.flush()

@@ -34,7 +34,10 @@ struct ConvSkP {
     const bf16_t* A; long long a_par_stride;          // stage images [parity][row tile][chunk][tap][MW * 8 KB]; elements per parity class
     const bf16_t* B0; const bf16_t* B1; int c0, ld0, ld1;   // input(s), zero-bordered NHWC; channels [0, c0) from B0, the rest from B1
     int nchunks;                                      // 32-channel chunks = C_in / 32
-    int nb, H, W, Wp, HpWp, npos;                     // input grid (= output grid; low-res grid for the Upsample parity classes)
+    int nb, H, W, Wp, Hp;                             // input grid (= output grid; low-res grid for the Upsample parity classes)
+    // position space: [sample][strip][H + 2][Ws + 2] - the image is cut into ns vertical strips of Ws columns, each carried with its
+    // two neighbour columns (ns = 1: the zero-bordered tensor itself); npos = nb * ns * HpWpe positions, tiles are NPX consecutive ones
+    int ns, Ws, Wpe, HpWpe, npos;
     int ntiles, rowtiles, npar;                       // pixel tiles, row tiles, parity classes (1 | 4); units = npar * rowtiles * ntiles
     int nhp;                                          // halo DMA pieces (16 positions each) per chunk
     int nfeat;
@@ -50,28 +53,32 @@ struct ConvSkP {
     unsigned long long* dbg;
 };
 
-template <int MW>
+// MW row blocks of 128 x NW wave64 per workgroup: <2, 8> 256 rows x 256 positions and <1, 8> 128 x 512, one persistent workgroup per CU
+// (160 KB of LDS); <1, 4> 128 x 256 with 80 KB, TWO workgroups per CU: one's prologue / epilogue runs under the other's K loop
+template <int MW, int NW = 8>
 struct CvSk {
-    static constexpr int NPX = 512 / MW;              // pixel positions per unit
+    static constexpr int NWN = NW / MW;               // waves along the positions
+    static constexpr int NPX = 64 * NWN;              // pixel positions per unit
     static constexpr int ROWS = 128 * MW;
     static constexpr int STAGE = 8192 * MW;           // bytes of one sub-step's weights
-    static constexpr int PW = MW;                     // DMA pieces per wave and stage
+    static constexpr int PW = 8 * MW / NW;            // DMA pieces per wave and stage
+    static constexpr bool LDS_TAB = NW == 8;          // fold tables in LDS (persistent workgroups) or read from global memory in the epilogue
     static constexpr int OFF_W = 0;
     static constexpr int OFF_TB = 4 * STAGE;          // [9][ROWS] fp32: bias + Tb[cls]
-    static constexpr int OFF_TG = OFF_TB + 9 * ROWS * 4;
-    static constexpr int OFF_MS = OFF_TG + 9 * ROWS * 4;     // [64][2] fp32: (alpha * rstd, mean * rstd) per sample
+    static constexpr int OFF_TG = OFF_TB + (LDS_TAB ? 9 * ROWS * 4 : 0);
+    static constexpr int OFF_MS = OFF_TG + (LDS_TAB ? 9 * ROWS * 4 : 0);     // [64][2] fp32: (alpha * rstd, mean * rstd) per sample
     static constexpr int MAXB = 64;
-    static constexpr int OFF_DUMMY = OFF_MS + MAXB * 8;      // landing zone of the DMA pieces issued past the end of a segment (keeps the counted waits uniform)
-    static constexpr int OFF_H = OFF_DUMMY + 1024;           // two halo buffers of nhp KB each
-    static constexpr int THREADS = 512;
-    static constexpr int NHW = MW == 2 ? 4 : 7;       // halo DMA pieces per wave and chunk (a fixed number: the counted waits are literals);
-    static constexpr int NHP_MAX = 8 * NHW;           // pieces past the halo's end repeat its last piece
+    static constexpr int OFF_H = OFF_MS + MAXB * 8;   // two halo buffers of nhp KB each
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int NHW = NW == 4 ? 6 : (MW == 2 ? 4 : 7);   // halo DMA pieces per wave and chunk (a fixed number: the counted waits are literals);
+    static constexpr int NHP_MAX = NW * NHW;          // pieces past the halo's end repeat its last piece
+    static constexpr int LDS_MAX = NW == 8 ? 160 * 1024 : 80 * 1024;
     __host__ __device__ static constexpr int lds_bytes(int nhp) { return OFF_H + 2 * nhp * 1024; }
     __host__ __device__ static constexpr int part_floats() { return ROWS * NPX; }
 };
 
 #ifdef UCDIR_TIMING
-#define SK_STAMP() do { if (dbg_on && dbg_n < 250) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SK_STAMP() do { if (dbg_on && dbg_n < 120) p.dbg[dbg_off + dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SK_STAMP() do {} while (0)
 #endif
@@ -87,6 +94,18 @@ struct SkSched {
     __host__ __device__ long long start(int g) const { return tc * g / G; }
 };
 
+// position q of the strip space -> sample, padded row, column inside the strip (0 and Ws + 1: the neighbour columns) and padded column
+// of the tensor
+__device__ __forceinline__ void sk_decode(const ConvSkP& p, int q, int& b, int& yp, int& xs, int& xpm) {
+    const int per_b = p.ns * p.HpWpe;
+    b = q / per_b;
+    int r = q - b * per_b;
+    int strip = 0;
+    if (p.ns > 1) { strip = r / p.HpWpe; r -= strip * p.HpWpe; }
+    yp = r / p.Wpe; xs = r - yp * p.Wpe;
+    xpm = strip * p.Ws + xs;
+}
+
 // LDS reads the compiler does not count (an epilogue that runs while the next segment's LDS-DMAs are in flight must not be made to
 // wait for them: hipcc puts vmcnt(0) in front of every LDS read it knows about while an LDS-DMA is outstanding)
 __device__ __forceinline__ void lds_read8f_asm(f32x2_t& v, unsigned addr) {
@@ -97,22 +116,22 @@ __device__ __forceinline__ void lds_read8f_asm(f32x2_t& v, unsigned addr) {
 // Shared by the conv kernel (LDS_TAB: fold tables and per-sample scalars in LDS, read by uncounted inline asm) and the finish kernel
 // (tables straight from bias / Tb / Tg in global memory, scalars in its own LDS): identical arithmetic - a unit finished in-kernel
 // or from partial tiles gives the same bits for the same accumulator values.
-template <int MW, bool LDS_TAB>
+template <int MW, int NW, int TAB, bool MS_ASM>
 __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[4][2],
-                                            int par, int rt, int tile, int wm, int wn, int lane) {
-    using L = CvSk<MW>;
+                                            int par, int rt, int tile, int wm, int wn, int lane, unsigned tab_base = 0) {
+    using L = CvSk<MW, NW>;
     const int hh = lane >> 5, l31 = lane & 31;
     const int act = p.act;
     const int py = par >> 1, pxp = par & 1;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int q = tile * L::NPX + wn * 64 + n * 32 + l31;          // position in [B][H + 2][W + 2]
-        const int b = q / p.HpWp, r = q - b * p.HpWp;
-        const int yp = r / p.Wp, xp = r - yp * p.Wp;
-        const bool valid = q < p.npos && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
+        const int q = tile * L::NPX + wn * 64 + n * 32 + l31;          // position in [B][strip][H + 2][Ws + 2]
+        int b, yp, xs, xp;
+        sk_decode(p, q, b, yp, xs, xp);
+        const bool valid = q < p.npos && yp >= 1 && yp <= p.H && xs >= 1 && xs <= p.Ws && xp <= p.W;
         const int bb = b < p.nb ? b : p.nb - 1;
         float ra, mr;
-        if (LDS_TAB) {
+        if (MS_ASM) {
             f32x2_t m2;
             lds_read8f_asm(m2, (unsigned)(L::OFF_MS + 8 * bb));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -122,7 +141,7 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
         } else { ra = ms_plain[2 * bb]; mr = ms_plain[2 * bb + 1]; }
         const int y = yp - 1, x = xp - 1;
         const int cls = p.npar > 1 ? 4 : (y <= 0 ? 0 : (y >= p.H - 1 ? 2 : 1)) * 3 + (x <= 0 ? 0 : (x >= p.W - 1 ? 2 : 1));
-        long long opos = q;
+        long long opos = ((long long)b * p.Hp + yp) * p.Wp + xp;
         if (p.npar > 1) opos = ((long long)b * (2 * p.H + 2) + (2 * y + py + 1)) * (2 * p.W + 2) + (2 * x + pxp + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -130,7 +149,32 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
             const int ch = wm * 128 + f * 32 + 16 * hh;                // channel within the row tile
             const int fo = rt * L::ROWS + ch;
             f32x4_t b4[4], g4v[4];
-            if (LDS_TAB) {
+            if (TAB == 2) {
+                // segments of 128 floats at tab_base: bias | Tb[0..8] | Tg[0..8] of this row tile (DMA'd into the idle halo buffer under the last chunk)
+                const unsigned ba = tab_base + (unsigned)(ch * 4), ta = ba + (unsigned)((1 + cls) * 512), ga = ba + (unsigned)((10 + cls) * 512);
+                f32x4_t bb4[4];
+                lds_read16f_asm<0>(bb4[0], ba); lds_read16f_asm<16>(bb4[1], ba); lds_read16f_asm<32>(bb4[2], ba); lds_read16f_asm<48>(bb4[3], ba);
+                if (p.fold) {
+                    lds_read16f_asm<0>(b4[0], ta); lds_read16f_asm<16>(b4[1], ta); lds_read16f_asm<32>(b4[2], ta); lds_read16f_asm<48>(b4[3], ta);
+                    lds_read16f_asm<0>(g4v[0], ga); lds_read16f_asm<16>(g4v[1], ga); lds_read16f_asm<32>(g4v[2], ga); lds_read16f_asm<48>(g4v[3], ga);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(bb4[g4]));
+                if (p.fold) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(b4[g4]), "+v"(g4v[g4]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = p.bias ? bb4[g4][e] : 0.f;
+                        b4[g4][e] = p.fold ? bv + b4[g4][e] : bv;
+                        g4v[g4][e] = p.fold ? g4v[g4][e] : 0.f;
+                    }
+            } else if (TAB == 1) {
                 const unsigned ta = (unsigned)(L::OFF_TB + (cls * L::ROWS + ch) * 4), ga = ta + (unsigned)(L::OFF_TG - L::OFF_TB);
                 lds_read16f_asm<0>(b4[0], ta); lds_read16f_asm<16>(b4[1], ta); lds_read16f_asm<32>(b4[2], ta); lds_read16f_asm<48>(b4[3], ta);
                 lds_read16f_asm<0>(g4v[0], ga); lds_read16f_asm<16>(g4v[1], ga); lds_read16f_asm<32>(g4v[2], ga); lds_read16f_asm<48>(g4v[3], ga);
@@ -214,9 +258,9 @@ __device__ __forceinline__ void sk_sample_table(const ConvSkP& p, float* ms, int
     }
 }
 // (bias + Tb, Tg) of row tile rt, all nine border classes
-template <int MW>
+template <int MW, int NW>
 __device__ __forceinline__ void sk_row_table(const ConvSkP& p, unsigned char* smem, int rt, int tid) {
-    using L = CvSk<MW>;
+    using L = CvSk<MW, NW>;
     float* tb = reinterpret_cast<float*>(smem + L::OFF_TB);
     float* tg = reinterpret_cast<float*>(smem + L::OFF_TG);
     for (int i = tid; i < 9 * L::ROWS; i += L::THREADS) {
@@ -230,11 +274,11 @@ __device__ __forceinline__ void sk_row_table(const ConvSkP& p, unsigned char* sm
     }
 }
 
-template <int MW, int NTAPS>
-__global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
-    using L = CvSk<MW>;
+template <int MW, int NW, int NTAPS>
+__global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
+    using L = CvSk<MW, NW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NWN = 8 / MW;                                      // waves along the pixel dimension
+    constexpr int NWN = L::NWN;                                      // waves along the pixel dimension
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
@@ -245,12 +289,14 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
 #ifdef UCDIR_TIMING
-    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == 5);
+    // two stamped workgroups: one of the first round (entries 0 ..), one of the last (entries 128 ..)
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3 || lid == (int)gridDim.x - 3) && (lane == 0) && (wave == NW - 1);
+    const int dbg_off = lid == (int)gridDim.x - 3 ? 128 : 0;
     int dbg_n = 0;
 #endif
     SK_STAMP();
     const int G = gridDim.x;
-    const int Wp = p.Wp, nch = p.nchunks, nhp = p.nhp;
+    const int Wp = p.Wpe, nch = p.nchunks, nhp = p.nhp;              // (Wp: row pitch of the strip space)
     const int HB = nhp * 1024;                                       // bytes of one halo buffer
     constexpr int NHW = L::NHW;                                      // halo pieces per wave and chunk
     constexpr int TA = NTAPS - 3 > 1 ? NTAPS - 3 : 1;                // sub-steps of a chunk whose S point may carry halo pieces: the
@@ -278,12 +324,12 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
     };
     if (NTAPS == 9) set_bx(0, 0);
     // halo staging: piece i = 16 positions; lane -> (position 16 i + lane / 4, physical 16-byte chunk lane & 3 = logical ^ ((pos >> 2) & 3));
-    // this wave's j-th piece is piece j * 8 + wave (past the halo's end: a repeat of its last piece)
+    // this wave's j-th piece is piece j * NW + wave (past the halo's end: a repeat of its last piece)
     int hpos[NHW], hdst[NHW]; unsigned hsw[NHW];
 #pragma unroll
     for (int j = 0; j < NHW; ++j) {
-        int i = j * 8 + wave; i = i < nhp ? i : nhp - 1;
-        hpos[j] = 16 * i + (lane >> 2) - Wp - 1;                     // + q0: position in the tensor
+        int i = j * NW + wave; i = i < nhp ? i : nhp - 1;
+        hpos[j] = 16 * i + (lane >> 2) - Wp - 1;                     // + q0: position in the strip space
         hsw[j] = (unsigned)(((lane & 3) ^ (((16 * i + (lane >> 2)) >> 2) & 3)) << 3);
         hdst[j] = L::OFF_H + i * 1024;
     }
@@ -329,6 +375,18 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
         for (int j = 0; j < L::PW; ++j)
             stage16(a_seg + (long long)k * (L::STAGE / 2) + j * 512, smem + L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024, lane);
     };
+    // one-shot kind: the fold tables of the segment's row tile (bias | Tb[9] | Tg[9], 128 floats each: 19 half pieces) take the place of the
+    // halo pieces that the last chunk would request for a chunk that does not exist - same instruction count, idle halo buffer
+    constexpr int NTP = 10;
+    auto issue_table = [&](int rt, int i, int buf) {                 // piece i = segments 2 i (lanes 0 - 31) and 2 i + 1 (lanes 32 - 63)
+        const int seg = 2 * i + (lane >> 5);
+        const float* src = reinterpret_cast<const float*>(p.A);      // (a missing array: anything readable; the epilogue does not look at it)
+        if (seg == 0 || seg > 18) { if (p.bias) src = p.bias + rt * L::ROWS; }
+        else if (seg < 10) { if (p.fold) src = p.Tb + (long long)(seg - 1) * p.tab_ld + rt * L::ROWS; }
+        else if (p.fold) src = p.Tg + (long long)(seg - 10) * p.tab_ld + rt * L::ROWS;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + (lane & 31) * 4), (LDS_AS void*)(smem + L::OFF_H + buf * HB + i * 1024), 16, 0, 0);
+    };
+    int hb0 = 0;                                                     // halo buffer of the segment's first chunk
     auto prefetch = [&](const Seg& s) {                              // halo of the first chunk and stages 0 .. 3 of segment s
         if (NTAPS != 9) set_bx(s.par >> 1, s.par & 1);
         const int q0 = s.tile * L::NPX;
@@ -336,22 +394,34 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
         for (int j = 0; j < NHW; ++j) {
             int q = q0 + hpos[j];
             q = q < 0 ? 0 : (q >= p.npos ? p.npos - 1 : q);
-            hq[j] = (unsigned)q;
+            int b, yp, xs, xp;
+            sk_decode(p, q, b, yp, xs, xp);
+            xp = xp < p.Wp ? xp : p.Wp - 1;                          // (a ragged last strip)
+            hq[j] = (unsigned)((b * p.Hp + yp) * p.Wp + xp);
         }
         a_seg = p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512 + lane * 8;
         seg_cb = s.cb;
 #pragma unroll
-        for (int j = 0; j < NHW; ++j) issue_halo(s.cb, j, 0);
+        for (int j = 0; j < NHW; ++j) issue_halo(s.cb, j, hb0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) issue_stage(s.cb * NTAPS + k, k);
     };
 
-    sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS), 0, p.nb, wave, 8, lane);
     Seg cur = next_segment();
     if (!cur.ok) return;
     int rt_cur = cur.rt;
-    sk_row_table<MW>(p, smem, cur.rt, tid);
     prefetch(cur);
+    // (alpha * rstd, mean * rstd): persistent workgroups build the whole list once, one-shot ones the few samples their tile spans
+    auto sample_range = [&](const Seg& s) {
+        const int per_b = p.ns * p.HpWpe;
+        const int b0 = (s.tile * L::NPX) / per_b;
+        int b1 = (s.tile * L::NPX + L::NPX - 1) / per_b + 1; b1 = b1 < p.nb ? b1 : p.nb;
+        if (b0 < b1) sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS) + 2 * b0, b0, b1, wave, NW, lane);
+    };
+    if (L::LDS_TAB) {
+        sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS), 0, p.nb, wave, NW, lane);
+        sk_row_table<MW, NW>(p, smem, cur.rt, tid);
+    } else sample_range(cur);
 
 #pragma unroll 1
     while (true) {
@@ -384,11 +454,12 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
             lds_read16_asm<0>(fb[jj][1], b1);
         };
         __builtin_amdgcn_sched_barrier(0);
-        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, 0u);
-        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, 0u);
+        unsigned bcur = hb0 ? (unsigned)HB : 0u;                     // halo buffer offset of the current chunk (0 | HB)
+        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, bcur);
+        reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, bcur);
 
         int h = 0;                                                   // sub-step counter of this segment
-        unsigned bcur = 0;                                           // halo buffer offset of the current chunk (0 | HB)
+        const bool want_tab = !L::LDS_TAB && cb == 0 && ce == nch;   // (a partial segment has no epilogue)
 #pragma unroll 1
         for (int c = cb; c < ce; ++c) {
             const unsigned bnext = bcur ? 0u : (unsigned)HB;
@@ -415,7 +486,11 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
                     asm volatile("s_barrier" ::: "memory");
                     if constexpr (t < TA) {
                         constexpr int j0 = t * HPER < NHW ? t * HPER : NHW, j1 = (t + 1) * HPER < NHW ? (t + 1) * HPER : NHW;
-                        static_for<j0, j1>([&](auto jc) { issue_halo(cn, decltype(jc)::value, bnext ? 1 : 0); });
+                        static_for<j0, j1>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt, j * NW + wave, bnext ? 1 : 0);
+                            else issue_halo(cn, j, bnext ? 1 : 0);
+                        });
                     }
                     issue_stage(cb * NTAPS + h + 4, h & 3);
                 }
@@ -442,12 +517,14 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
         asm volatile("s_barrier" ::: "memory");
         SK_STAMP();
         // the next segment's first halo and stages fly under this segment's epilogue (same row tile: its LDS reads are uncounted inline asm)
-        const bool same_rt = nxt.ok && nxt.rt == rt_cur;
+        const bool same_rt = nxt.ok && (nxt.rt == rt_cur || !L::LDS_TAB);
+        const unsigned tab_base = (unsigned)L::OFF_H + bcur;         // (bcur: the buffer behind the last chunk's = where its S points put the tables)
+        hb0 = bcur ? 0 : 1;                                          // the next segment starts in the other one
         if (same_rt) prefetch(nxt);
         __builtin_amdgcn_sched_barrier(0);
 
         if (cb == 0 && ce == nch) {
-            sk_epilogue<MW, true>(p, smem, nullptr, acc, cur.par, cur.rt, cur.tile, wm, wn, lane);
+            sk_epilogue<MW, NW, L::LDS_TAB ? 1 : 2, true>(p, smem, nullptr, acc, cur.par, cur.rt, cur.tile, wm, wn, lane, tab_base);
         } else {
             // raw accumulators, accumulator layout: [wave][f][n][reg / 4][lane][4] fp32 - coalesced 16-byte stores
             float* pw = p.partial + ((long long)(2 * lid + (cur.first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
@@ -464,26 +541,27 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const ConvSkP p) {
         if (!nxt.ok) break;
         if (!same_rt) {                                              // another row tile: its fold tables replace the current ones behind the epilogue
             __syncthreads();
-            sk_row_table<MW>(p, smem, nxt.rt, tid);
+            if (L::LDS_TAB) sk_row_table<MW, NW>(p, smem, nxt.rt, tid);
             rt_cur = nxt.rt;
             prefetch(nxt);
         }
+        if (!L::LDS_TAB) { __syncthreads(); sample_range(nxt); }
         cur = nxt;
     }
 #ifdef UCDIR_TIMING
-    if (dbg_on) p.dbg[255] = dbg_n;
+    if (dbg_on) p.dbg[dbg_off ? 254 : 255] = dbg_n;
 #endif
 }
 
 // Second half of a stream-K launch: sums the partial tiles of every cut unit in ascending workgroup order (fixed: bit-reproducible)
 // and runs the epilogue.  grid = (8, stream-K units): one WAVE per workgroup, the slice of the unit that wave `blockIdx.x` of the conv
-// kernel owns (688 small workgroups instead of 86 large ones: the pass is bound by reading ~1 MB per unit); units that one
+// kernel owns (many small workgroups: the pass is bound by reading the partial tiles, ~80 MB per launch); units that one
 // workgroup computed whole exit at once.
-template <int MW>
+template <int MW, int NW>
 __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int G) {
-    using L = CvSk<MW>;
+    using L = CvSk<MW, NW>;
     __shared__ float ms[2 * L::MAXB];
-    constexpr int NWN = 8 / MW;
+    constexpr int NWN = L::NWN;
     const int lane = threadIdx.x;
     const int wave = blockIdx.x;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -504,7 +582,13 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         if (p.npar > 1) { par = uu / per_par; uu -= par * per_par; }
         rt = uu / p.ntiles; tile = uu - rt * p.ntiles;
     }
-    sk_sample_table(p, ms, 0, p.nb, 0, 1, lane);                     // (a few samples; the loads of the first partial tile fly meanwhile)
+    {
+        const int per_b = p.ns * p.HpWpe;                            // the few samples this wave's 64 positions span
+        const int q0 = tile * L::NPX + wn * 64;
+        const int b0 = q0 / per_b;
+        int b1 = (q0 + 63) / per_b + 1; b1 = b1 < p.nb ? b1 : p.nb;
+        if (b0 < b1) sk_sample_table(p, ms + 2 * b0, b0, b1, 0, 1, lane);
+    }
     f32x16_t acc[4][2];
     bool have = false;
     for (; g < G && sch.start(g) < b; ++g) {
@@ -523,5 +607,5 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         have = true;
     }
     __syncthreads();
-    sk_epilogue<MW, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane);
+    sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane);
 }

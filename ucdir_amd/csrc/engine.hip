@@ -105,8 +105,8 @@ struct ConvW {
     bf16_t* Aws128 = nullptr;                            // 3x3 128 -> 64 + res_conv: A fragments of conv_ws128_kernel (72 steps, then the res_conv's 8)
     bf16_t* Aqkv = nullptr;                              // 1x1 C -> 3C of SelfAttention: fragments of qkv_ws_kernel (qkv_ws.hip.h)
     bf16_t* Atile = nullptr;                             // 3x3: the weight stages of conv3x3_halo_kernel<TM> as contiguous 16 KB blocks (pack_conv_tiled)
-    bf16_t* Ask = nullptr; bf16_t* Ask_up = nullptr;     // 3x3 / Upsample parity classes: stage images of conv_sk_kernel (pack_conv_sk); sk_mw rows of 128 per tile
-    int sk_mw = 0; long long sk_up_stride = 0;
+    bf16_t* Ask[2] = {nullptr, nullptr}; bf16_t* Ask_up[2] = {nullptr, nullptr};   // 3x3 / Upsample parity classes: stage images of conv_sk_kernel
+    long long sk_up_stride[2] = {0, 0};                  // (pack_conv_sk) for row tiles of 128 ([0]) and 256 rows ([1])
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -129,8 +129,8 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
     if (ks == 3 && cin == 64 && cout == 64 && P.Kpad == 576) W.Aws = pool.upload(pack_conv_ws(P));
     if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && P.rows_pad % W.TM == 0) W.Atile = pool.upload(pack_conv_tiled(P, W.TM));
     if (ks == 3 && cin % 32 == 0 && P.Kpad == 9 * cin && cout % 128 == 0) {
-        W.sk_mw = cout % 256 == 0 ? 2 : 1;                // 256-row x 256-position units, or 128 x 512 (C_out = 128, 384)
-        W.Ask = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, W.sk_mw));
+        W.Ask[0] = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 1));
+        if (cout % 256 == 0) W.Ask[1] = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 2));
     }
     if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
@@ -138,12 +138,12 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
 static void upload_upconv(DevPool& pool, ConvW& W, const float* w, const float* bias) {
     PackedConv P = pack_upconv(w, bias, W.cout, W.cin, W.TM);
     W.Aup = pool.upload(P.A); W.Kup = P.Kpad;
-    if (W.cin % 32 == 0 && W.cout % 128 == 0) {
-        W.sk_mw = W.cout % 256 == 0 ? 2 : 1;
-        std::vector<bf16_t> img = pack_conv_sk(P.A, 4, P.rows_pad, P.Kpad, W.cin, 4, W.sk_mw);
-        W.sk_up_stride = (long long)((img.size() - (size_t)4 * 4 * W.sk_mw * 2 * 512) / 4);   // (the image ends in four stages of padding)
-        W.Ask_up = pool.upload(img);
-    }
+    for (int mw = 1; mw <= 2; ++mw)
+        if (W.cin % 32 == 0 && W.cout % (128 * mw) == 0) {
+            std::vector<bf16_t> img = pack_conv_sk(P.A, 4, P.rows_pad, P.Kpad, W.cin, 4, mw);
+            W.sk_up_stride[mw - 1] = (long long)((img.size() - (size_t)4 * 4 * mw * 2 * 512) / 4);   // (the image ends in four stages of padding)
+            W.Ask_up[mw - 1] = pool.upload(img);
+        }
 }
 static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, const float* gamma, const float* beta, int C) {
     PackedAkgm P = pack_akgm(wsp, bsp, gamma, beta, C, 0);
@@ -209,8 +209,9 @@ static void ensure_kernel_attrs() {
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
-    set_lds_attr(conv_sk_kernel<2, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 4>, 160 * 1024);
-    set_lds_attr(conv_sk_kernel<1, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<1, 4>, 160 * 1024);
+    set_lds_attr(conv_sk_kernel<2, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 8, 4>, 160 * 1024);
+    set_lds_attr(conv_sk_kernel<1, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<1, 8, 4>, 160 * 1024);
+    set_lds_attr(conv_sk_kernel<1, 4, 9>, 80 * 1024); set_lds_attr(conv_sk_kernel<1, 4, 4>, 80 * 1024);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -420,24 +421,34 @@ static int choose_usplit(int nblk) {
 
 // ---- conv_sk_kernel (conv_sk.hip.h): persistent stream-K 3x3 conv / Upsample parity classes on 256-row tiles -------------------------
 static std::atomic<int> g_convsk{-1};          // -1: environment (UCDIR_NO_CONV_SK) + work threshold, 0: off, 1: forced (tests: any size)
-template <int MW>
+template <int MW, int NW>
 static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, int mode) {
-    using L = CvSk<MW>;
-    const bf16_t* img = upph ? w.Ask_up : w.Ask;
+    using L = CvSk<MW, NW>;
+    const bf16_t* img = upph ? w.Ask_up[MW - 1] : w.Ask[MW - 1];
+    if (!img) return false;
     const int cin = x0.C + (x1 ? x1->C : 0);
-    const int H = x0.H, W = x0.W, Wp = W + 2, HpWp = (H + 2) * Wp, B = x0.B;
+    const int H = x0.H, W = x0.W, Wp = W + 2, Hp = H + 2, B = x0.B;
     if (B > L::MAXB) return false;
-    const long long npos = (long long)B * HpWp;
-    if (npos * (long long)(cin > y.C ? cin : y.C) * (upph ? 4 : 1) >= (1LL << 31)) return false;      // 32-bit element offsets in the kernel
     const int NPX = L::NPX;
-    const int nhp = (NPX + 2 * Wp + 2 + 15) / 16;
-    if (L::lds_bytes(nhp) > 160 * 1024 || nhp > L::NHP_MAX) return false;                            // halo buffers; fixed halo piece count per wave
+    // vertical strips: the fewest whose halo (NPX + 2 (Ws + 2) + 2 positions of 64 bytes, two buffers) fits the workgroup's LDS and the
+    // kernel's fixed number of halo pieces
+    int ns = 1, Ws = W, nhp = 0;
+    for (;; ++ns) {
+        Ws = (W + ns - 1) / ns;
+        nhp = (NPX + 2 * (Ws + 2) + 2 + 15) / 16;
+        if (nhp <= L::NHP_MAX && L::lds_bytes(nhp) <= L::LDS_MAX) break;
+        if (Ws <= 8) return false;
+    }
+    const int Wpe = Ws + 2, HpWpe = Hp * Wpe;
+    const long long npos = (long long)B * ns * HpWpe;
+    if ((long long)B * Hp * Wp * (long long)(cin > y.C ? cin : y.C) * (upph ? 4 : 1) >= (1LL << 31) || npos >= (1LL << 30)) return false;   // 32-bit offsets in the kernel
     ConvSkP p; std::memset(&p, 0, sizeof(p));
-    p.A = img; p.a_par_stride = upph ? w.sk_up_stride : 0;
+    p.A = img; p.a_par_stride = upph ? w.sk_up_stride[MW - 1] : 0;
     p.B0 = x0.p; p.ld0 = x0.C; p.c0 = x0.C;
     if (x1) { p.B1 = x1->p; p.ld1 = x1->C; }
     p.nchunks = cin / 32;
-    p.nb = B; p.H = H; p.W = W; p.Wp = Wp; p.HpWp = HpWp; p.npos = (int)npos;
+    p.nb = B; p.H = H; p.W = W; p.Wp = Wp; p.Hp = Hp;
+    p.ns = ns; p.Ws = Ws; p.Wpe = Wpe; p.HpWpe = HpWpe; p.npos = (int)npos;
     p.ntiles = (int)((npos + NPX - 1) / NPX); p.rowtiles = (w.cout + L::ROWS - 1) / L::ROWS; p.npar = upph ? 4 : 1;
     p.nhp = nhp; p.nfeat = w.cout;
     p.alpha = 1.f; p.fold = (!upph && w.fold) ? 1 : 0; p.act = act;
@@ -451,18 +462,27 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     p.out = y.p; p.out_ld = y.C;
     if (want_stats) p.stats_out = y.stats;
     p.units = p.npar * p.rowtiles * p.ntiles;
-    int G = num_cus(); if (G > SK_MAX_GRID) G = SK_MAX_GRID;
     const long long work = (long long)p.units * p.nchunks;           // chunks of 9 (4) sub-steps
-    if (mode < 0 && (work < 3LL * G || p.units * 8 < G)) return false;   // too little for one workgroup per CU: the one-shot kernels (split-K) are faster
-    if (G > work) G = (int)work;
-    p.ndp = (p.units / G) * G;
+    int G;
+    if (NW == 8) {                                                   // one persistent workgroup per CU, stream-K remainder
+        G = num_cus(); if (G > SK_MAX_GRID) G = SK_MAX_GRID;
+        if (mode < 0 && (work < 3LL * G || p.units * 8 < G)) return false;   // too little for one workgroup per CU: the one-shot kernels (split-K) are faster
+        if (G > work) G = (int)work;
+        p.ndp = (p.units / G) * G;
+    } else {                                                         // one workgroup per unit, two resident per CU
+        G = p.units; p.ndp = p.units;
+        static const int persist = getenv("UCDIR_SK_PERSIST") ? atoi(getenv("UCDIR_SK_PERSIST")) : 0;   // experiment: ranges of whole units on persist x CUs workgroups
+        if (persist > 0 && G > persist * num_cus()) G = persist * num_cus();
+        if (g_persist_grid > 0) { G = g_persist_grid < p.units ? (int)g_persist_grid : p.units; if (2 * G > 2 * SK_MAX_GRID) G = SK_MAX_GRID; p.ndp = (p.units / G) * G; }   // (tests: ranges and a stream-K remainder)
+        if (mode < 0 && p.units < num_cus()) return false;
+    }
     p.partial = splitk_scratch();
     const size_t lds = L::lds_bytes(nhp);
     const int nsk = p.units - p.ndp;
     auto go = [&]() {
-        if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, 4>), dim3(G), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_sk_kernel<MW, 9>), dim3(G), dim3(512), lds, st, p);
-        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW>), dim3(8, nsk), dim3(64), 0, st, p, G);
+        if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 4>), dim3(G), dim3(L::THREADS), lds, st, p);
+        else hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 9>), dim3(G), dim3(L::THREADS), lds, st, p);
+        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(NW, nsk), dim3(64), 0, st, p, G);
     };
 #ifdef UCDIR_TIMING
     {
@@ -474,15 +494,17 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         unsigned long long h[256];
         HIPC(hipStreamSynchronize(st));
         HIPC(hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost));
-        const int n = (int)h[255];
-        fprintf(stderr, "CONV_SK TIMING n=%d:", n);
-        for (int i = 1; i < n && i < 255; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
-        fprintf(stderr, "\n");
+        for (int w2 = 0; w2 < 2; ++w2) {
+            const int n = (int)h[255 - w2];
+            fprintf(stderr, "CONV_SK TIMING %s units=%d grid=%d n=%d: start %llu |", w2 ? "last-round" : "first-round", p.units, G, n, h[128 * w2] - (h[0] < h[128] ? h[0] : h[128]));
+            for (int i = 1; i < n && i < 120; ++i) fprintf(stderr, " %llu", h[128 * w2 + i] - h[128 * w2 + i - 1]);
+            fprintf(stderr, "\n");
+        }
         return true;
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = upph ? 126 : 125;
+        ProfEntry e; e.key = (NW == 8 ? 125 : 127) + (upph ? 1 : 0);
         const double cols = (double)H * W * B * (upph ? 4.0 : 1.0);
         e.flops = 2.0 * 9 * cin * (double)w.cout * cols;             // reference op count (the parity classes execute 4 / 9 of it)
         e.bytes = ((double)cin * H * W * 2 + (double)w.cout * cols / B * 2) * B + 9.0 * cin * w.cout * 2;
@@ -496,15 +518,19 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     HIPC(hipGetLastError());
     return true;
 }
+// g_convsk: -1 environment (UCDIR_NO_CONV_SK, UCDIR_CONV_SK_MODE) + work thresholds; 0 off; 1: persistent stream-K workgroups of 8 waves forced;
+// 2: one-shot 4-wave workgroups (two per CU) forced
 static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st) {
     static const bool env_on = !getenv("UCDIR_NO_CONV_SK");
+    static const int env_kind = getenv("UCDIR_CONV_SK_MODE") ? atoi(getenv("UCDIR_CONV_SK_MODE")) : 2;
     const int mode = g_convsk.load();
     if (mode == 0 || (mode < 0 && !env_on)) return false;
-    if (!(upph ? w.Ask_up : w.Ask)) return false;
     if (x0.C % 32 || (x1 && x1->C % 32) || y.C % 8) return false;
-    if (w.sk_mw == 2) return try_conv_sk_mw<2>(w, x0, x1, y, upph, act, res, want_stats, st, mode);
-    if (w.sk_mw == 1) return try_conv_sk_mw<1>(w, x0, x1, y, upph, act, res, want_stats, st, mode);
-    return false;
+    const int kind = mode > 0 ? mode : env_kind;
+    const int fm = mode > 0 ? 1 : -1;
+    if (kind == 2) return try_conv_sk_mw<1, 4>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
+    if (w.cout % 256 == 0) return try_conv_sk_mw<2, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
+    return try_conv_sk_mw<1, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
 }
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
