@@ -137,6 +137,29 @@ def test_conv_stream_k(args, kind):
 
 
 @pytest.mark.parametrize("args", [
+    (2, 24, 40, 128, 64, 128),       # 192 -> 128 with its res_conv: one row tile
+    (3, 18, 18, 512, 256, 512),      # four row tiles, tiles spanning samples
+    (1, 72, 72, 256, 128, 256),      # two strips of 36 columns
+    (2, 30, 44, 64, 0, 128),         # no concatenation, ragged
+], ids=["rows128", "rows512_samples", "strips", "plain_ragged"])
+def test_conv_stream_k_with_res_conv(args):
+    """conv1 (GroupNorm fold + swish) with the block's 1x1 res_conv as the LAST workgroups of the same conv_sk launch (4-wave kind):
+    both outputs against torch, statistics of conv1's output, run to run bit-identical."""
+    B, H, W, c0, c1, cout = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"convsk", 2))
+    try:
+        (m, keys) = _profile_keys(L, lambda: C.conv_res_case(B, H, W, c0, c1, cout, seed=7))
+        m2 = C.conv_res_case(B, H, W, c0, c1, cout, seed=7)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
+    assert 127 in keys and 100 not in keys and 0 not in keys, keys     # one launch: no separate 1x1 GEMM
+    assert not m["nan"] and m["rel_rms"] < OP_TOL and not m["res_nan"] and m["res_rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0) and m["stats_rel"] < 1e-3, m
+    assert m2 == m, (m, m2)
+
+
+@pytest.mark.parametrize("args", [
     (3, 32, 48, 64, 64, 64, 4096),     # conv_ws128: 8 x 16 tiles, one tile per workgroup, all border tiles
     (3, 64, 80, 64, 64, 64, 7),        # persistent ranges crossing sample boundaries (grid forced to 7 workgroups)
     (2, 288, 288, 64, 64, 64, 0),      # the network's level-0 size (ups.17 / ups.18)

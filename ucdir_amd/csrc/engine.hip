@@ -107,6 +107,7 @@ struct ConvW {
     bf16_t* Atile = nullptr;                             // 3x3: the weight stages of conv3x3_halo_kernel<TM> as contiguous 16 KB blocks (pack_conv_tiled)
     bf16_t* Ask[2] = {nullptr, nullptr}; bf16_t* Ask_up[2] = {nullptr, nullptr};   // 3x3 / Upsample parity classes: stage images of conv_sk_kernel
     long long sk_up_stride[2] = {0, 0};                  // (pack_conv_sk) for row tiles of 128 ([0]) and 256 rows ([1])
+    bf16_t* Ask1x1 = nullptr;                            // 1x1 (a block's res_conv): one-tap stage image, row tiles of 128: rides in conv1's conv_sk launch
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
@@ -132,6 +133,7 @@ static ConvW upload_conv(DevPool& pool, const float* w, const float* bias, const
         W.Ask[0] = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 1));
         if (cout % 256 == 0) W.Ask[1] = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 9, 2));
     }
+    if (ks == 1 && cin % 32 == 0 && P.Kpad == cin && cout % 128 == 0 && gamma == nullptr) W.Ask1x1 = pool.upload(pack_conv_sk(P.A, 1, P.rows_pad, P.Kpad, cin, 1, 1));
     if (ks == 1 && cout == 3 * cin && gamma != nullptr && (cin == 256 || cin == 512) && P.Kpad == cin && P.rows_pad >= cout) W.Aqkv = pool.upload(pack_qkv_ws(P, cin));
     return W;
 }
@@ -422,7 +424,7 @@ static int choose_usplit(int nblk) {
 // ---- conv_sk_kernel (conv_sk.hip.h): persistent stream-K 3x3 conv / Upsample parity classes on 256-row tiles -------------------------
 static std::atomic<int> g_convsk{-1};          // -1: environment (UCDIR_NO_CONV_SK) + work threshold, 0: off, 1: forced (tests: any size)
 template <int MW, int NW>
-static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, int mode) {
+static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, int mode, bool* did_res, Act* res_out, const ConvW* wres) {
     using L = CvSk<MW, NW>;
     const bf16_t* img = upph ? w.Ask_up[MW - 1] : w.Ask[MW - 1];
     if (!img) return false;
@@ -474,7 +476,17 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         static const int persist = getenv("UCDIR_SK_PERSIST") ? atoi(getenv("UCDIR_SK_PERSIST")) : 0;   // experiment: ranges of whole units on persist x CUs workgroups
         if (persist > 0 && G > persist * num_cus()) G = persist * num_cus();
         if (g_persist_grid > 0) { G = g_persist_grid < p.units ? (int)g_persist_grid : p.units; if (2 * G > 2 * SK_MAX_GRID) G = SK_MAX_GRID; p.ndp = (p.units / G) * G; }   // (tests: ranges and a stream-K remainder)
-        if (mode < 0 && p.units < num_cus()) return false;
+        // measured per layer at B = 16 (tools/conv_layers.py): ahead of conv3x3_halo<128> from 4 chunks of K on (Upsample classes: 8 - a class
+        // has only four sub-steps per halo chunk) once every CU has a workgroup
+        if (mode < 0 && (p.units < num_cus() || p.nchunks < (upph ? 8 : 4))) return false;
+    }
+    if (did_res) *did_res = false;
+    if (NW == 4 && MW == 1 && !upph && res_out && wres && wres->Ask1x1 && wres->cout == w.cout && G == p.units && p.ndp == p.units) {
+        // the block's 1x1 res_conv as the grid's last workgroups (one per (row tile, pixel tile)): same input, its own weights and output
+        p.alt_units = p.rowtiles * p.ntiles; p.alt_A = wres->Ask1x1; p.alt_bias = wres->bias;
+        p.alt_out = res_out->p; p.alt_out_ld = res_out->C;
+        G += p.alt_units;
+        if (did_res) *did_res = true;
     }
     p.partial = splitk_scratch();
     const size_t lds = L::lds_bytes(nhp);
@@ -508,6 +520,7 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         const double cols = (double)H * W * B * (upph ? 4.0 : 1.0);
         e.flops = 2.0 * 9 * cin * (double)w.cout * cols;             // reference op count (the parity classes execute 4 / 9 of it)
         e.bytes = ((double)cin * H * W * 2 + (double)w.cout * cols / B * 2) * B + 9.0 * cin * w.cout * 2;
+        if (p.alt_units) { e.flops += 2.0 * cin * (double)w.cout * cols; e.bytes += 2.0 * cin * w.cout + 2.0 * w.cout * cols; }
         e.dH = H; e.dW = W; e.dCin = cin; e.dCout = w.cout;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();
         HIPC(hipEventRecord(e.e0, st));
@@ -520,7 +533,7 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
 }
 // g_convsk: -1 environment (UCDIR_NO_CONV_SK, UCDIR_CONV_SK_MODE) + work thresholds; 0 off; 1: persistent stream-K workgroups of 8 waves forced;
 // 2: one-shot 4-wave workgroups (two per CU) forced
-static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st) {
+static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, bool* did_res, Act* res_out, const ConvW* wres) {
     static const bool env_on = !getenv("UCDIR_NO_CONV_SK");
     static const int env_kind = getenv("UCDIR_CONV_SK_MODE") ? atoi(getenv("UCDIR_CONV_SK_MODE")) : 2;
     const int mode = g_convsk.load();
@@ -528,9 +541,9 @@ static bool try_conv_sk(const ConvW& w, const Act& x0, const Act* x1, Act& y, bo
     if (x0.C % 32 || (x1 && x1->C % 32) || y.C % 8) return false;
     const int kind = mode > 0 ? mode : env_kind;
     const int fm = mode > 0 ? 1 : -1;
-    if (kind == 2) return try_conv_sk_mw<1, 4>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
-    if (w.cout % 256 == 0) return try_conv_sk_mw<2, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
-    return try_conv_sk_mw<1, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm);
+    if (kind == 2) return try_conv_sk_mw<1, 4>(w, x0, x1, y, upph, act, res, want_stats, st, fm, did_res, res_out, wres);
+    if (w.cout % 256 == 0) return try_conv_sk_mw<2, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm, did_res, nullptr, nullptr);
+    return try_conv_sk_mw<1, 8>(w, x0, x1, y, upph, act, res, want_stats, st, fm, did_res, nullptr, nullptr);
 }
 
 // conv (3x3 stride 1 / down / up, or 1x1) from padded activations to a padded activation
@@ -581,7 +594,11 @@ static bool run_conv(const ConvW& w, const Act& x0, const Act* x1, Act& y, int m
     if (want_stats) {
         p.stats_out = y.stats;
     }
-    if (halo && !nchw_out && try_conv_sk(w, x0, x1, y, upph, act, res, want_stats, st)) return false;    // (a res_conv is then a launch of its own)
+    if (halo && !nchw_out) {
+        bool sk_res = false;
+        static const bool sk_tail = !getenv("UCDIR_NO_TAIL_RES");
+        if (try_conv_sk(w, x0, x1, y, upph, act, res, want_stats, st, &sk_res, sk_tail ? res_out : nullptr, wres)) return sk_res;
+    }
 #ifdef UCDIR_TIMING
     static unsigned long long* dbgbuf = nullptr;
     if (!dbgbuf) HIPC(hipMalloc((void**)&dbgbuf, 256 * 8));
