@@ -473,12 +473,16 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         p.ndp = (p.units / G) * G;
     } else {                                                         // one workgroup per unit, two resident per CU
         G = p.units; p.ndp = p.units;
-        static const int persist = getenv("UCDIR_SK_PERSIST") ? atoi(getenv("UCDIR_SK_PERSIST")) : 0;   // experiment: ranges of whole units on persist x CUs workgroups
-        if (persist > 0 && G > persist * num_cus()) G = persist * num_cus();
+        static const int persist = getenv("UCDIR_SK_PERSIST") ? atoi(getenv("UCDIR_SK_PERSIST")) : 0;   // experiment: ranges of whole units on 2 x CUs workgroups from `persist` units per workgroup on
+        if (persist > 0 && G >= persist * 2 * num_cus()) G = 2 * num_cus();
         if (g_persist_grid > 0) { G = g_persist_grid < p.units ? (int)g_persist_grid : p.units; if (2 * G > 2 * SK_MAX_GRID) G = SK_MAX_GRID; p.ndp = (p.units / G) * G; }   // (tests: ranges and a stream-K remainder)
         // measured per layer at B = 16 (tools/conv_layers.py): ahead of conv3x3_halo<128> from 4 chunks of K on (Upsample classes: 8 - a class
         // has only four sub-steps per halo chunk) once every CU has a workgroup
-        if (mode < 0 && (p.units < num_cus() || p.nchunks < (upph ? 8 : 4))) return false;
+        static const int ksplit_env = getenv("UCDIR_SK_KSPLIT") ? atoi(getenv("UCDIR_SK_KSPLIT")) : 0;   // (2: 1024 -> 512 at 18^2 90 vs 102 us per launch, but 35.56 vs 35.67 img/s end to end: the finish launch; off)
+        if (ksplit_env > 1 && g_persist_grid <= 0 && p.units * ksplit_env <= 2 * num_cus() && p.nchunks >= 16 * ksplit_env && !upph) {
+            // few long units (the 18^2 level): every unit's K range cut into ksplit parts, one workgroup each; the finish kernel sums them
+            G = p.units * ksplit_env; p.ndp = 0;
+        } else if (mode < 0 && (p.units < num_cus() || p.nchunks < (upph ? 8 : 4))) return false;
     }
     if (did_res) *did_res = false;
     if (NW == 4 && MW == 1 && !upph && res_out && wres && wres->Ask1x1 && wres->cout == w.cout && G == p.units && p.ndp == p.units) {
