@@ -39,6 +39,10 @@ def bench_name(k):
         return "conv_ws<128->64>+res"
     if "conv_ws_kernel" in k:
         return "conv_ws<64>"
+    m = re.search(r"conv_sk_kernel<(\d+), (\d+), (\d+)>", k)
+    if m:                                           # <MW, waves, taps>: taps 4 = the parity classes of Upsample + conv
+        waves, taps = int(m.group(2)), int(m.group(3))
+        return ("upconv_sk" if taps == 4 else "conv_sk") + f"<{waves} waves>" + ("+res" if waves == 4 and taps == 9 else "")
     m = re.search(r"conv3x3_halo_kernel<(\d+)(?:, (true|false))?>", k)
     if m:
         # <128> / <64> also carry the parity-decomposed Upsample launches; <64, true> = conv1 + fused res_conv
