@@ -66,28 +66,3 @@ for (H, c0, c1, cout, mode) in SHAPES:
         out[2][0], out[2][1] * 1e3, out[2][2], out[0][1] / max(out[2][1], 1e-9), out[0][3], out[1][3], out[2][3]))
     sys.stdout.flush()
 
-# ---- AKGM tails (64 channels per group): one-shot akgm_halo_stage vs conv_sk's AKGM mode ----------------------------------
-if not flt or "akgm" in flt:
-    for (H, Cc) in [(36, 512), (18, 512), (72, 256)]:
-        g = C.rng(0)
-        h = torch.randn(B, Cc, H, H, generator=g).cuda(); att = torch.randn(B, 8, H, H, generator=g).cuda(); res = torch.randn(B, Cc, H, H, generator=g).cuda()
-        wsp = (torch.randn(8 * Cc, Cc // 8, 3, 3, generator=g) * 0.1).numpy().copy(); bsp = np.zeros(8 * Cc, np.float32)
-        gm = np.ones(Cc, np.float32); bt = np.zeros(Cc, np.float32)
-        y = torch.empty(B, Cc, H, H, device="cuda")
-        out = []
-        for sk in (0, 1):
-            ulib.check(L.ucdir_debug_flag(b"akgmsk", sk))
-            best = None
-            for r in range(reps + 1):
-                ulib.check(L.ucdir_profile_enable(1 if r else 0))
-                ulib.check(L.ucdir_op_akgm(C._p(h), C._p(att), C._p(res), B, Cc, H, H, C._hp(wsp), C._hp(bsp), C._hp(gm), C._hp(bt), C._p(y), C._hp(None), C._st()))
-                ulib.check(L.ucdir_profile_enable(0))
-                if r:
-                    rows = [x for x in prof_read() if x[0] in (111, 112, 113, 114, 115, 116)]
-                    t = sum(x[2] for x in rows)
-                    best = t if best is None or t < best else best
-                    key = rows[0][0] if rows else -1
-            out.append((key, best, 2.0 * 9 * Cc * Cc * H * H * B / (best * 1e-3) / 1e12, float(y.abs().mean())))
-        ulib.check(L.ucdir_debug_flag(b"akgmsk", -1))
-        print("akgm %d^2 C=%d: old %3d %7.1f us %6.1f TF | conv_sk %3d %7.1f us %6.1f TF x%.2f  (|y| %.4f %.4f)" % (
-            H, Cc, out[0][0], out[0][1] * 1e3, out[0][2], out[1][0], out[1][1] * 1e3, out[1][2], out[0][1] / out[1][1], out[0][3], out[1][3]))
