@@ -173,7 +173,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the denoiser has no CPU path")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # under a torch.distributed launcher (the driver's `python -m torch.distributed.run ... bench.py`) RCCL is initialised even for one
+    # rank: the launch line of a scaling run is then exercised end to end on a one-GPU box (barriers, the max over ranks, and in
+    # patch mode the per-step all-gather branch)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -270,6 +274,7 @@ def patch_mode(args, net, dev, dist, rank, world, T):
     H, W = args.height, args.width
     if dist is not None:
         net.denoise_fn.patch_group = dist.group.WORLD
+        net.denoise_fn.patch_force_gather = True              # (a one-rank group under the launcher still runs the collective)
     net.noise_seed = 1234                                     # every rank applies the identical sampler update
     net.denoise_fn.patch_timers = [] if dist is not None else None    # (start, end) events of every all-gather
     if args.patch_batch:

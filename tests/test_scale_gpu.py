@@ -425,6 +425,35 @@ def test_rccl_all_gather_branch_on_one_gpu():
     assert same and n_gather == 4
 
 
+def test_bench_under_the_distributed_launcher_on_one_gpu(tmp_path):
+    """The launch line of the driver's scaling run, on the one GPU this box has: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P bench.py --gpus 1 ...` for the headline mode and for the patch mode.
+    RCCL initialises, the barriers / max-over-ranks run, the patch mode's per-step all-gather runs on device buffers, and rank 0
+    prints ONE parseable JSON line with the scaling keys (round-3 verdict: no N > 1 hardware run exists; this is what can be
+    exercised without a second GPU)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(base + ["--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                               "--timesteps", "4", "--batch", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["frac"] > 0, d
+    r = subprocess.run(base + ["--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "patch", "--steps", "1",
+                               "--warmup", "0", "--timesteps", "2", "--height", "1100", "--width", "1300"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["scaling"] == "strong" and c["windows_per_rank"] == [c["windows_per_step"]] and len(c["all_gather_ms_per_step_per_rank"]) == 1, c
+    assert c["all_gather_ms_per_step_per_rank"][0] > 0, c          # the collective ran (one-rank RCCL group, gather branch)
+
+
 def test_in_place_weight_update_reaches_the_engine(sid_net):
     """an in-place parameter update (optimizer.step / EMA copy through .data) must re-pack the engine's
     weights before the next image - the per-image signature check notices it without mark_weights_dirty()."""
