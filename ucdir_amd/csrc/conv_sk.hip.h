@@ -424,30 +424,25 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     const unsigned a_lane = L::OFF_W + (4 * wm) * 2048 + lane * 16;
     // B: tap t, MFMA tile n: halo position hp = 64 wn + 32 n + l31 + ky Wp + kx; 64 bytes per position, 16-byte chunk
     // (2 jj + hh) ^ ((hp >> 2) & 3): address(jj = 1) = address(jj = 0) ^ 32.  (Upsample parity classes: per segment.)
-    unsigned bx[NTAPS][2];
+    // (the second MFMA tile of a wave is 32 positions = 2048 bytes further with the same swizzle: an immediate offset, not a register)
+    unsigned bx[NTAPS];
     auto set_bx = [&](int py, int pxp) {
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             int ky, kx;
             if (NTAPS == 9) { ky = t / 3; kx = t - 3 * ky; } else { ky = py + (t >> 1); kx = pxp + (t & 1); }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int hp = wn * 64 + n * 32 + l31 + ky * Wp + kx;
-                bx[t][n] = L::OFF_H + (hp << 6) + (((hh ^ (hp >> 2)) & 3) << 4);
-            }
+            const int hp = wn * 64 + l31 + ky * Wp + kx;
+            bx[t] = L::OFF_H + (hp << 6) + (((hh ^ (hp >> 2)) & 3) << 4);
         }
     };
     if (NTAPS == 9) set_bx(0, 0);
     // halo staging: piece i = 16 positions; lane -> (position 16 i + lane / 4, physical 16-byte chunk lane & 3 = logical ^ ((pos >> 2) & 3));
     // this wave's j-th piece is piece j * NW + wave (past the halo's end: a repeat of its last piece)
-    int hpos[NHW], hdst[NHW]; unsigned hsw[NHW];
-#pragma unroll
-    for (int j = 0; j < NHW; ++j) {
-        int i = j * NW + wave; i = i < nhp ? i : nhp - 1;
-        hpos[j] = 16 * i + (lane >> 2) - Wp - 1;                     // + q0: position in the strip space
-        hsw[j] = (unsigned)(((lane & 3) ^ (((16 * i + (lane >> 2)) >> 2) & 3)) << 3);
-        hdst[j] = L::OFF_H + i * 1024;
-    }
+    // (per lane: one base position and one source swizzle - the chunk XOR ((16 i + lane / 4) >> 2) & 3 = (lane >> 4) & 3 does not depend on the
+    // piece; the piece index i of (j, wave) is wave-uniform)
+    const int hpos0 = (lane >> 2) - Wp - 1;                         // + 16 i + q0: position in the strip space
+    const unsigned hsw = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+    auto piece_of = [&](int j) { const int i = j * NW + wave; return i < nhp ? i : nhp - 1; };
 
     const SkSched sch(p.units, p.ndp, nch, G);
     const long long c_beg = sch.start(lid), c_end = sch.start(lid + 1);      // stream-K chunk range of this workgroup
@@ -484,8 +479,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         int ch = c * 32;
         const bf16_t* src; int ld;
         if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
-        const unsigned off = hq[j] * (unsigned)ld + hsw[j] + (unsigned)ch;
-        stage16(src + off, smem + hdst[j] + buf * HB, lane);
+        const unsigned off = hq[j] * (unsigned)ld + hsw + (unsigned)ch;
+        stage16(src + off, smem + L::OFF_H + piece_of(j) * 1024 + buf * HB, lane);
     };
     auto issue_stage = [&](int k, int slot) {                        // stage k of the segment's (parity, row tile); past its end: whatever follows
 #pragma unroll                                                       // in the image (the image is padded by four stages) into a slot nobody reads any more
@@ -509,7 +504,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         const int q0 = s.tile * L::NPX;
 #pragma unroll
         for (int j = 0; j < NHW; ++j) {
-            int q = q0 + hpos[j];
+            int q = q0 + hpos0 + 16 * piece_of(j);
             q = q < 0 ? 0 : (q >= p.npos ? p.npos - 1 : q);
             int b, yp, xs, xp;
             sk_decode(p, q, b, yp, xs, xp);
@@ -566,9 +561,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
             lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aa);
             lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aa);
             lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aa);
-            const unsigned b0 = (bx[t][0] + boff) ^ (jj << 5), b1 = (bx[t][1] + boff) ^ (jj << 5);
+            const unsigned b0 = (bx[t] + boff) ^ (jj << 5);
             lds_read16_asm<0>(fb[jj][0], b0);
-            lds_read16_asm<0>(fb[jj][1], b1);
+            lds_read16_asm<2048>(fb[jj][1], b0);
         };
         __builtin_amdgcn_sched_barrier(0);
         unsigned bcur = hb0 ? (unsigned)HB : 0u;                     // halo buffer offset of the current chunk (0 | HB)
