@@ -87,6 +87,13 @@ struct CvSk {
 #define SK_STAMP() do {} while (0)
 #endif
 
+// one LDS-DMA piece with a wave-uniform (SGPR) base and a 32-bit per-lane byte offset: no 64-bit VALU address arithmetic per piece (the
+// builtin always takes a per-lane 64-bit pointer).  hipcc does not count it (cdna guide 5.7): the kernel's waits are counted by hand anyway;
+// M0 (the LDS destination) is written inside the statement.
+__device__ __forceinline__ void sk_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void sk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -473,19 +480,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
 
     // per-segment state of the DMA streams
     unsigned hq[NHW];                                                // clamped tensor positions of this wave's halo pieces
-    const bf16_t* a_seg = nullptr;                                   // this lane's source of stage 0 of the segment (+ k * STAGE / 2)
+    const unsigned char* a_seg = nullptr;                            // wave-uniform source of this wave's pieces of stage 0 of the segment (+ k * STAGE bytes)
+    const unsigned lane16 = (unsigned)lane * 16u;
     int seg_cb = 0;
     auto issue_halo = [&](int c, int j, int buf) {                   // piece j of chunk c into halo buffer buf
         int ch = c * 32;
         const bf16_t* src; int ld;
         if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
-        const unsigned off = hq[j] * (unsigned)ld + hsw + (unsigned)ch;
-        stage16(src + off, smem + L::OFF_H + piece_of(j) * 1024 + buf * HB, lane);
+        sk_dma16(src + ch, (hq[j] * (unsigned)ld + hsw) * 2u, (unsigned)(L::OFF_H + piece_of(j) * 1024 + buf * HB));
     };
     auto issue_stage = [&](int k, int slot) {                        // stage k of the segment's (parity, row tile); past its end: whatever follows
 #pragma unroll                                                       // in the image (the image is padded by four stages) into a slot nobody reads any more
         for (int j = 0; j < L::PW; ++j)
-            stage16(a_seg + (long long)k * (L::STAGE / 2) + j * 512, smem + L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024, lane);
+            sk_dma16(a_seg + (long long)k * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024));
     };
     // one-shot kind: the fold tables of the segment's row tile (bias | Tb[9] | Tg[9], 128 floats each: 19 half pieces) take the place of the
     // halo pieces that the last chunk would request for a chunk that does not exist - same instruction count, idle halo buffer
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
             xp = xp < p.Wp ? xp : p.Wp - 1;                          // (a ragged last strip)
             hq[j] = (unsigned)((b * p.Hp + yp) * p.Wp + xp);
         }
-        a_seg = p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512 + lane * 8;
+        a_seg = reinterpret_cast<const unsigned char*>(p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512);
         seg_cb = s.cb;
 #pragma unroll
         for (int j = 0; j < NHW; ++j) issue_halo(s.cb, j, hb0);
