@@ -479,15 +479,25 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     };
 
     // per-segment state of the DMA streams
-    unsigned hq[NHW];                                                // clamped tensor positions of this wave's halo pieces
+    unsigned hq[NHW];                                                // this wave's halo pieces: per-lane BYTE offsets in the tensor whose row pitch is ld_cur
+    int ld_cur = 0;                                                  // (position * ld_cur + swizzle) * 2; re-scaled when the chunk sequence changes tensor
+    const bf16_t* hsrc = nullptr;                                    // wave-uniform source of the chunk whose halo is being requested (tensor + channel)
+    auto halo_chunk = [&](int c) {                                   // once per chunk, not per piece
+        int ch = c * 32;
+        const bool first = ch < p.c0;
+        const int ld = first ? p.ld0 : p.ld1;
+        hsrc = first ? p.B0 + ch : p.B1 + (ch - p.c0);
+        if (ld != ld_cur) {
+#pragma unroll
+            for (int j = 0; j < NHW; ++j) hq[j] = ((((hq[j] >> 1) - hsw) / (unsigned)ld_cur) * (unsigned)ld + hsw) * 2u;
+            ld_cur = ld;
+        }
+    };
     const unsigned char* a_seg = nullptr;                            // wave-uniform source of this wave's pieces of stage 0 of the segment (+ k * STAGE bytes)
     const unsigned lane16 = (unsigned)lane * 16u;
     int seg_cb = 0;
-    auto issue_halo = [&](int c, int j, int buf) {                   // piece j of chunk c into halo buffer buf
-        int ch = c * 32;
-        const bf16_t* src; int ld;
-        if (ch < p.c0) { src = p.B0; ld = p.ld0; } else { src = p.B1; ld = p.ld1; ch -= p.c0; }
-        sk_dma16(src + ch, (hq[j] * (unsigned)ld + hsw) * 2u, (unsigned)(L::OFF_H + piece_of(j) * 1024 + buf * HB));
+    auto issue_halo = [&](int j, int buf) {                          // piece j of the chunk of halo_chunk() into halo buffer buf
+        sk_dma16(hsrc, hq[j], (unsigned)(L::OFF_H + piece_of(j) * 1024 + buf * HB));
     };
     auto issue_stage = [&](int k, int slot) {                        // stage k of the segment's (parity, row tile); past its end: whatever follows
 #pragma unroll                                                       // in the image (the image is padded by four stages) into a slot nobody reads any more
@@ -518,10 +528,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
             xp = xp < p.Wp ? xp : p.Wp - 1;                          // (a ragged last strip)
             hq[j] = (unsigned)((b * p.Hp + yp) * p.Wp + xp);
         }
+        ld_cur = s.cb * 32 < p.c0 ? p.ld0 : p.ld1;
+#pragma unroll
+        for (int j = 0; j < NHW; ++j) hq[j] = (hq[j] * (unsigned)ld_cur + hsw) * 2u;
+        halo_chunk(s.cb);
         a_seg = reinterpret_cast<const unsigned char*>(p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512);
         seg_cb = s.cb;
 #pragma unroll
-        for (int j = 0; j < NHW; ++j) issue_halo(s.cb, j, hb0);
+        for (int j = 0; j < NHW; ++j) issue_halo(j, hb0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) issue_stage(s.cb * NTAPS + k, k);
     };
@@ -583,6 +597,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         for (int c = cb; c < ce; ++c) {
             const unsigned bnext = bcur ? 0u : (unsigned)HB;
             const int cn = c + 1 < ce ? c + 1 : c;                   // (behind the last chunk: its own halo again, into the OTHER buffer, which nobody reads any more)
+            halo_chunk(cn);
             static_for<0, NTAPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int tn = (t + 1) % NTAPS;
@@ -608,7 +623,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
                         static_for<j0, j1>([&](auto jc) {
                             constexpr int j = decltype(jc)::value;
                             if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt, j * NW + wave, bnext ? 1 : 0);
-                            else issue_halo(cn, j, bnext ? 1 : 0);
+                            else issue_halo(j, bnext ? 1 : 0);
                         });
                     }
                     issue_stage(cb * NTAPS + h + 4, h & 3);
