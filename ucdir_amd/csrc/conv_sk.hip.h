@@ -602,14 +602,29 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int tn = (t + 1) % NTAPS;
                 constexpr int tm1 = (t + NTAPS - 1) % NTAPS;
+                // A unit's eight MFMAs in program order with the NEXT-BUT-ONE unit's fragment reads (and, in a sub-step's second unit, the S
+                // point's DMA pieces) placed in their shadows: a wave issues in order, so an instruction behind the cluster would wait for
+                // all eight (a lone wave per SIMD ran the cluster-then-reads order at 54 % of the matrix pipe).  A fragment register is
+                // re-requested right behind the last MFMA that reads it; sched_barrier pins the order.
+                const unsigned boffn = tn == 0 ? bnext : bcur;
+                const unsigned aan = a_lane + (unsigned)(((h + 1) & 3) * L::STAGE);        // sub-step h + 1: slot, halo buffer
+                auto unit = [&](auto jc, auto&& shadow) {
+                    constexpr int jj = decltype(jc)::value;
+                    const unsigned b0 = (bx[tn] + boffn) ^ (jj << 5);
+#define SK_MF(f, n) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[jj][f], fb[jj][n], acc[f][n], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                    SK_MF(0, 0); shadow(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(1, 0); shadow(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(2, 0); shadow(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(3, 0); lds_read16_asm<0>(fb[jj][0], b0); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(0, 1); lds_read16_asm<0 * 2048 + jj * 1024>(fa[jj][0], aan); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(1, 1); lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aan); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(2, 1); lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aan); __builtin_amdgcn_sched_barrier(0);
+                    SK_MF(3, 1); lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aan); lds_read16_asm<2048>(fb[jj][1], b0); __builtin_amdgcn_sched_barrier(0);
+#undef SK_MF
+                };
                 // ---- unit (t, 0) ----
                 lgkm_wait_asm<6>();                                  // R(t, 0) landed (R(t, 1) may be in flight)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][f], fb[0][n], acc[f][n], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                reads(std::integral_constant<int, tn>{}, std::integral_constant<int, 0>{}, h + 1, tn == 0 ? bnext : bcur);
+                unit(std::integral_constant<int, 0>{}, [&](auto) {});
                 // ---- unit (t, 1) ----
                 lgkm_wait_asm<6>();                                  // R(t, 1) landed: every read of stage h is complete
                 {
@@ -618,22 +633,30 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
                     constexpr int c1 = tm1 < TA ? j1p - j0p : 0;      // halo pieces S(t - 1) issued
                     sk_wait_vm<L::PW + c1>();
                     asm volatile("s_barrier" ::: "memory");
-                    if constexpr (t < TA) {
-                        constexpr int j0 = t * HPER < NHW ? t * HPER : NHW, j1 = (t + 1) * HPER < NHW ? (t + 1) * HPER : NHW;
-                        static_for<j0, j1>([&](auto jc) {
-                            constexpr int j = decltype(jc)::value;
-                            if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt, j * NW + wave, bnext ? 1 : 0);
-                            else issue_halo(j, bnext ? 1 : 0);
-                        });
-                    }
-                    issue_stage(cb * NTAPS + h + 4, h & 3);
                 }
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][f], fb[1][n], acc[f][n], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                reads(std::integral_constant<int, tn>{}, std::integral_constant<int, 1>{}, h + 1, tn == 0 ? bnext : bcur);
+                // the S point's DMA pieces: halo pieces first, then the stage (a later wait for the stage then covers the halo pieces in front of
+                // it), spread over the shadows of the first three MFMAs
+                unit(std::integral_constant<int, 1>{}, [&](auto sc) {
+                    constexpr int sidx = decltype(sc)::value;
+                    constexpr int j0 = t < TA ? (t * HPER < NHW ? t * HPER : NHW) : 0, j1 = t < TA ? ((t + 1) * HPER < NHW ? (t + 1) * HPER : NHW) : 0;
+                    constexpr int nh = j1 - j0;                       // halo pieces of this S point; then PW stage pieces
+                    // piece list: [halo j0 .. j1) [stage 0 .. PW): piece index q goes to shadow min(q * 3 / total, 2)
+                    constexpr int total = nh + L::PW;
+                    static_for<0, total>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        constexpr int sh = q * 3 / total;
+                        if constexpr (sh == sidx) {
+                            if constexpr (q < nh) {
+                                constexpr int j = j0 + q;
+                                if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt, j * NW + wave, bnext ? 1 : 0);
+                                else issue_halo(j, bnext ? 1 : 0);
+                            } else {
+                                constexpr int j = q - nh;
+                                sk_dma16(a_seg + (long long)(cb * NTAPS + h + 4) * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + (h & 3) * L::STAGE + (wave * L::PW + j) * 1024));
+                            }
+                        }
+                    });
+                });
                 ++h;
             });
             bcur = bnext;
