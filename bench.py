@@ -97,7 +97,21 @@ class LaunchProfile:
         return rows
 
 
-def roofline_record(rows, whole_tflops=None):
+def sustained_matrix_rate(L, ulib):
+    """Matrix-core rate this box sustains on operands like the conv kernels' (ucdir_matrix_rate: MFMAs only, ~4 ms bursts, after the
+    timed region): the clock the chip holds under matrix load depends on the operand bits, so the practical roof sits below `peak`."""
+    import ctypes
+    import torch
+    out = {}
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name, rnd in (("random_operands", 1), ("small_integer_operands", 0)):
+        v = ctypes.c_double(0.0)
+        ulib.check(L.ucdir_matrix_rate(15000, rnd, ctypes.byref(v), st))
+        out[name] = v.value
+    return out
+
+
+def roofline_record(rows, whole_tflops=None, sustained=None):
     """`roofline` object of the JSON line for the instantiation with the largest total time."""
     if not rows:
         return None
@@ -120,6 +134,11 @@ def roofline_record(rows, whole_tflops=None):
     if whole_tflops is not None:
         roof["forward_tflops_whole"] = whole_tflops
         roof["forward_frac_whole"] = whole_tflops / MFMA_BF16_PEAK_TFLOPS      # all launches of a forward against the dense bf16 peak
+    if sustained:
+        # measured in this run, NOT the `peak` that `frac` is priced against: what v_mfma_f32_32x32x16_bf16 alone reaches on this box
+        roof["sustained_peak"] = {"unit": "TFLOP/s", **{k: round(v, 1) for k, v in sustained.items()},
+                                  "frac_of_random_operand_rate": ach / sustained["random_operands"],
+                                  "source": "ucdir_matrix_rate (MFMA-only kernel, two waves per SIMD, no memory traffic), after the timed region"}
     return roof
 
 
@@ -245,7 +264,7 @@ def main():
     if rank == 0:
         fwd_flops = net.denoise_fn.forward_flops()          # algorithmic FLOPs of one B-sample forward
         value = world * B * args.steps / elapsed
-        roof = roofline_record(rows, fwd_flops * T * args.steps / elapsed / 1e12)
+        roof = roofline_record(rows, fwd_flops * T * args.steps / elapsed / 1e12, sustained_matrix_rate(L, ulib))
         rec = {"metric": "restored images/sec at 50-step p_sample_loop, 256x256 SID", "value": value,
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -346,7 +365,7 @@ def patch_mode(args, net, dev, dist, rank, world, T):
                           "windows_per_rank": [int(v[0].item()) for v in infos],
                           "all_gather_ms_per_step_per_rank": [round(float(v[1].item()), 4) for v in infos],
                           "workspace_bytes_rank0": int(ws)},
-               "roofline": roofline_record(rows)}
+               "roofline": roofline_record(rows, sustained=sustained_matrix_rate(L, ulib))}
         print(json.dumps(rec))
     if dist is not None:
         dist.barrier()

@@ -149,6 +149,12 @@ int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double
                            double* bytes, int32_t* nrows, void* stream);
 /* algorithmic FLOPs of one forward at the prepared shape (2*MAC, reference op count) */
 double  ucdir_forward_flops(const ucdir_ctx* ctx);
+/* Matrix-core rate this device sustains (bench.py's `roofline.sustained_peak`; nothing on the reference side corresponds to it):
+ * a kernel of v_mfma_f32_32x32x16_bf16 only - eight accumulator tiles per wave fed from four A and two B fragments held in
+ * registers, two waves per SIMD on every CU, no memory traffic - run for `iters` x 8 MFMAs per wave; best of three launches in
+ * *tflops.  random = 1: operands drawn like the conv kernels' (weights ~0.03 sigma, activations ~1 sigma); 0: small integers
+ * (the clock, hence the rate, depends on how many operand bits toggle: 1.75-1.8 against 2.45 PFLOP/s on the boxes measured). */
+int32_t ucdir_matrix_rate(int32_t iters, int32_t random, double* tflops, void* stream);
 
 /* ---- UNetSeeInDark predictor (model/ucdir.py:310-416): initial restoration = guide = residual base.
  * `name` = reference state_dict key without the "predictor." prefix ("conv1_1.weight", "upv6.bias", ...).

@@ -2,6 +2,7 @@
 
 Tolerances are stated in tests/hip_checks.py: bf16 operands / fp32 accumulate / bf16 activations.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -35,7 +36,6 @@ def sid_net():
 
 def _profile_keys(L, fn):
     """Run fn() with the library's per-launch event profiler on and return {key: launches} of the kernels it dispatched."""
-    import ctypes
     C.ulib.check(L.ucdir_profile_enable(1))
     try:
         r = fn()
@@ -664,3 +664,17 @@ def test_persistent_kernel_switches_agree_at_a_size_where_they_engage():
             assert not m[b]["nan"] and m[b]["rel_rms"] < FWD_TOL, (tag, b, m[b])
     assert 113 in out["default"]["keys"] and 23 in out["default"]["keys"] and 24 in out["default"]["keys"], out["default"]["keys"]
     assert not any(k in out["oneshot"]["keys"] for k in (113, 114, 115, 23, 24, 105, 125)), out["oneshot"]["keys"]
+
+
+def test_matrix_rate_probe_is_plausible():
+    """ucdir_matrix_rate (bench.py's `roofline.sustained_peak`): an MFMA-only kernel cannot beat the dense bf16 peak of the
+    guide, and on conv-like operands the chip holds a lower clock than on small integers."""
+    L = C.ulib.load()
+    vals = []
+    for rnd in (1, 0):
+        v = ctypes.c_double(0.0)
+        C.ulib.check(L.ucdir_matrix_rate(4000, rnd, ctypes.byref(v), C._st()))
+        vals.append(v.value)
+    assert 800.0 < vals[0] <= vals[1] * 1.02 and vals[1] < 2600.0, vals
+    v = ctypes.c_double(0.0)
+    assert L.ucdir_matrix_rate(0, 1, ctypes.byref(v), C._st()) != 0        # bad argument: an error code, not a launch

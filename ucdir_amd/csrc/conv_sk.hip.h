@@ -615,24 +615,36 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
                     SK_MF(0, 0); shadow(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(1, 0); shadow(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(2, 0); shadow(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+#ifdef SK_ABL_NOREAD
+                    SK_MF(3, 0); SK_MF(0, 1); SK_MF(1, 1); SK_MF(2, 1); SK_MF(3, 1); (void)b0; (void)aan;
+#else
                     SK_MF(3, 0); lds_read16_asm<0>(fb[jj][0], b0); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(0, 1); lds_read16_asm<0 * 2048 + jj * 1024>(fa[jj][0], aan); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(1, 1); lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aan); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(2, 1); lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aan); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(3, 1); lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aan); lds_read16_asm<2048>(fb[jj][1], b0); __builtin_amdgcn_sched_barrier(0);
+#endif
 #undef SK_MF
                 };
                 // ---- unit (t, 0) ----
+#ifndef SK_ABL_NOREAD
                 lgkm_wait_asm<6>();                                  // R(t, 0) landed (R(t, 1) may be in flight)
+#endif
                 unit(std::integral_constant<int, 0>{}, [&](auto) {});
                 // ---- unit (t, 1) ----
+#ifndef SK_ABL_NOREAD
                 lgkm_wait_asm<6>();                                  // R(t, 1) landed: every read of stage h is complete
+#endif
                 {
                     // S point: stage h + 2 must be in LDS (requested two sub-steps ago); allowed in flight: the halo pieces of S(t - 1) and stage h + 3
                     constexpr int j0p = tm1 * HPER < NHW ? tm1 * HPER : NHW, j1p = (tm1 + 1) * HPER < NHW ? (tm1 + 1) * HPER : NHW;
                     constexpr int c1 = tm1 < TA ? j1p - j0p : 0;      // halo pieces S(t - 1) issued
+#ifndef SK_ABL_NODMA
                     sk_wait_vm<L::PW + c1>();
+#endif
+#ifndef SK_ABL_NOBAR
                     asm volatile("s_barrier" ::: "memory");
+#endif
                 }
                 // the S point's DMA pieces: halo pieces first, then the stage (a later wait for the stage then covers the halo pieces in front of
                 // it), spread over the shadows of the first three MFMAs
@@ -644,7 +656,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
                     constexpr int total = nh + L::PW;
                     static_for<0, total>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
+#ifdef SK_ABL_NODMA
+                        constexpr int sh = 99;
+#else
                         constexpr int sh = q * 3 / total;
+#endif
                         if constexpr (sh == sidx) {
                             if constexpr (q < nh) {
                                 constexpr int j = j0 + q;

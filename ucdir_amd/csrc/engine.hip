@@ -1734,6 +1734,27 @@ int32_t ucdir_profile_read(int32_t cap, int32_t* keys, int32_t* launches, double
     API_END
 }
 
+int32_t ucdir_matrix_rate(int32_t iters, int32_t random, double* tflops, void* stream) {
+    API_BEGIN
+    if (iters <= 0 || !tflops) throw std::runtime_error("ucdir_matrix_rate: iters > 0 and a result pointer are required");
+    hipStream_t st = (hipStream_t)stream;
+    static float* sink = nullptr;
+    if (!sink) HIPC(hipMalloc((void**)&sink, 4));
+    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    const int grid = 2 * num_cus();
+    float best = 1e30f;
+    for (int r = 0; r < 4; ++r) {                                    // (the first launch warms the clock)
+        HIPC(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(matrix_rate_kernel, dim3(grid), dim3(256), 0, st, iters, random, sink);
+        HIPC(hipEventRecord(e1, st)); HIPC(hipEventSynchronize(e1));
+        float ms = 0.f; HIPC(hipEventElapsedTime(&ms, e0, e1));
+        if (r && ms < best) best = ms;
+    }
+    HIPC(hipEventDestroy(e0)); HIPC(hipEventDestroy(e1));
+    *tflops = 2.0 * 32 * 32 * 16 * 8.0 * iters * 4 * grid / (best * 1e-3) / 1e12;
+    API_END
+}
+
 int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx) { return ctx ? ctx->apool.bytes + ctx->wpool.bytes : 0; }
 double ucdir_forward_flops(const ucdir_ctx* ctx) { return ctx ? ctx->flops : 0.0; }
 

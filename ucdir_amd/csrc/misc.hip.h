@@ -621,3 +621,36 @@ __global__ void maxpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict
         *reinterpret_cast<uint4*>(y + (((long long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C + c) = ov;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Matrix-core rate the device sustains (ucdir_matrix_rate; tools/mfma_peak.hip is the stand-alone version): MFMAs only, the
+// 4 x 2 fragment pattern of conv_sk_kernel's wave tile, operands resident in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void matrix_rate_kernel(int iters, int random, float* out) {
+    f32x16_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8_t a[4], b[2];
+    unsigned r = (threadIdx.x + 977u * blockIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            r = r * 1664525u + 1013904223u;
+            const float u = ((r >> 8) & 0xffff) / 65536.f + ((r >> 20) & 0xfff) / 4096.f - 1.f;
+            a[k][e] = (__bf16)(random ? u * 0.03f : (float)(threadIdx.x & 3));
+            if (k < 2) b[k][e] = (__bf16)(random ? u * 1.7f : (float)(threadIdx.x & 1));
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 12345.678f) out[0] = s;                   // (keeps the loop alive)
+}

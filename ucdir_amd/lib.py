@@ -51,6 +51,7 @@ _SIGS = {
     "ucdir_profile_read": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_double), POINTER(c_double),
                                      POINTER(c_double), POINTER(c_int32), c_void_p]),
     "ucdir_forward_flops": (c_double, [c_void_p]),
+    "ucdir_matrix_rate": (c_int32, [c_int32, c_int32, POINTER(c_double), c_void_p]),
     "ucdir_predictor_create": (c_int32, [c_int32, POINTER(c_void_p)]),
     "ucdir_predictor_destroy": (None, [c_void_p]),
     "ucdir_predictor_load_weight": (c_int32, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]),
