@@ -132,8 +132,10 @@ int64_t ucdir_workspace_bytes(const ucdir_ctx* ctx);
  * -1 = environment default (UCDIR_NO_FLASH).  "splitk": 1 / 0 / -1 the same for split-K and unit splits of
  * under-filled grids (UCDIR_SPLITK).  "persist_grid": n > 0 launches the persistent kernels (akgm_ws) with n workgroups
  * instead of one per compute unit, 0 restores the default.  "wsb": 1 routes the AKGM tails of 8 / 16 channels per group
- * through akgm_ws32_kernel<8 | 16> instead of akgm_ws_kernel (A/B and tests), 0 / -1 (UCDIR_WSB) as above.  Unknown names
- * are an error. */
+ * through akgm_ws32_kernel<8 | 16> instead of akgm_ws_kernel (A/B and tests), 0 / -1 (UCDIR_WSB) as above.  "convsk": 0 = 3x3 convs
+ * on conv3x3_halo (the round-3 dispatch), 1 = conv_sk_kernel's persistent 8-wave stream-K kind forced, 2 = its one-shot 4-wave kind
+ * forced (both regardless of the size thresholds: tests), -1 = environment default (UCDIR_NO_CONV_SK, UCDIR_CONV_SK_MODE).  Unknown
+ * names are an error. */
 int32_t ucdir_debug_flag(const char* name, int32_t value);
 /* Host-side launch planning, callable without a device (tests): what = "ksplit" -> the K-split factor conv3x3_halo would use
  * for a grid of `wgs` workgroups over `nchunks` 32-channel chunks of `steps_per_chunk` K steps producing `out_elems` outputs;
