@@ -183,6 +183,9 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         FA_STAMP();                                                 // [6k+2] K wait done
         __syncthreads();                                            // ... for every wave; PV(t-1) done: P, V't free
         FA_STAMP();                                                 // [6k+3] barrier A passed
+#ifdef FA_ABL_NODMA
+        if (t == 0)
+#endif
         issue_V(t);
         // ---- S^T = K Q^T --------------------------------------------------------------------------------------
         f32x4_t sacc[4];
@@ -199,8 +202,14 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+#ifndef FA_ABL_NOS
                 sacc[kt] = fa_mfma16(kf[kt], qf[ks], sacc[kt]);
+#else
+                if (ks == 0) sacc[kt] = fa_mfma16(kf[kt], qf[ks], sacc[kt]);
+#endif
+#ifndef FA_ABL_NOSREAD
                 if (ks + 1 < NKS) kf[kt] = *reinterpret_cast<const vec_t*>(kaddr(ks + 1, kt));
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -245,7 +254,9 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // V't(t) landed
         __syncthreads();                                            // P, alpha visible; every wave done with K(t)
         FA_STAMP();                                                 // [6k+6] V wait + barrier B passed
+#ifndef FA_ABL_NODMA
         if (t + 1 < ntiles) issue_K(t + 1);
+#endif
         // ---- O^T = alpha O^T + V't P^T ----------------------------------------------------------------------------
         {
             const float a0 = rowsc[64 * qh + l31], a1 = rowsc[64 * qh + 32 + l31];
@@ -264,7 +275,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn_kernel(const FlashP 
         // the other wave shares, not by this wave's read latency.  Kept in the plain form.)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
+#ifdef FA_ABL_NOPV
+        for (int k16 = 0; k16 < 1; ++k16) {
+#else
         for (int k16 = 0; k16 < 4; ++k16) {
+#endif
             vec_t pf[2], vf[NC];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) pf[qt] = *reinterpret_cast<const vec_t*>(Pl + vbase + ((32 * k16) ^ vx) + (64 * qh + 32 * qt) * 128);
