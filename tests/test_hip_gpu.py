@@ -141,7 +141,8 @@ def test_conv_stream_k(args, kind):
     (3, 18, 18, 512, 256, 512),      # four row tiles, tiles spanning samples
     (1, 72, 72, 256, 128, 256),      # two strips of 36 columns
     (2, 30, 44, 64, 0, 128),         # no concatenation, ragged
-], ids=["rows128", "rows512_samples", "strips", "plain_ragged"])
+    (16, 18, 18, 512, 512, 512),     # the bench configuration's 18^2 block: 100 units for 256 CUs -> every unit's K cut in two (finish kernel), res_conv still in the launch
+], ids=["rows128", "rows512_samples", "strips", "plain_ragged", "level4_ksplit"])
 def test_conv_stream_k_with_res_conv(args):
     """conv1 (GroupNorm fold + swish) with the block's 1x1 res_conv as the LAST workgroups of the same conv_sk launch (4-wave kind):
     both outputs against torch, statistics of conv1's output, run to run bit-identical."""

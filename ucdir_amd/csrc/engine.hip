@@ -466,6 +466,7 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     p.units = p.npar * p.rowtiles * p.ntiles;
     const long long work = (long long)p.units * p.nchunks;           // chunks of 9 (4) sub-steps
     int G;
+    bool ksplit_on = false;
     if (NW == 8) {                                                   // one persistent workgroup per CU, stream-K remainder
         G = num_cus(); if (G > SK_MAX_GRID) G = SK_MAX_GRID;
         if (mode < 0 && (work < 3LL * G || p.units * 8 < G)) return false;   // too little for one workgroup per CU: the one-shot kernels (split-K) are faster
@@ -478,27 +479,31 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         if (g_persist_grid > 0) { G = g_persist_grid < p.units ? (int)g_persist_grid : p.units; if (2 * G > 2 * SK_MAX_GRID) G = SK_MAX_GRID; p.ndp = (p.units / G) * G; }   // (tests: ranges and a stream-K remainder)
         // measured per layer at B = 16 (tools/conv_layers.py): ahead of conv3x3_halo<128> from 4 chunks of K on (Upsample classes: 8 - a class
         // has only four sub-steps per halo chunk) once every CU has a workgroup
-        static const int ksplit_env = getenv("UCDIR_SK_KSPLIT") ? atoi(getenv("UCDIR_SK_KSPLIT")) : 0;   // (2: 1024 -> 512 at 18^2 90 vs 102 us per launch, but 35.56 vs 35.67 img/s end to end: the finish launch; off)
-        if (ksplit_env > 1 && g_persist_grid <= 0 && p.units * ksplit_env <= 2 * num_cus() && p.nchunks >= 16 * ksplit_env && !upph) {
-            // few long units (the 18^2 level): every unit's K range cut into ksplit parts, one workgroup each; the finish kernel sums them
-            G = p.units * ksplit_env; p.ndp = 0;
+        // few long units (the 18^2 level at B = 16: 100 units of 144 - 288 sub-steps for 256 CUs): every unit's K range cut in two, one
+        // workgroup each, the finish kernel sums the halves in part order.  Per launch incl. the finish pass, tools/conv_layers.py:
+        // 1024 -> 512 101 -> 83 us, 512 -> 512 62 -> 59 us (three and four parts: 97 / 87 us - every part pays its own prologue and
+        // partial-tile store).  UCDIR_SK_KSPLIT=<n> (0 / 1: off) for A/B.  Not below 64 units: B = 1 keeps its split-K path.
+        static const int ksplit_env = getenv("UCDIR_SK_KSPLIT") ? atoi(getenv("UCDIR_SK_KSPLIT")) : 2;
+        if (ksplit_env > 1 && g_persist_grid <= 0 && p.units >= 64 && p.units * ksplit_env <= 2 * num_cus() && p.nchunks >= 8 * ksplit_env && !upph) {
+            G = p.units * ksplit_env; p.ndp = 0; ksplit_on = true;
         } else if (mode < 0 && (p.units < num_cus() || p.nchunks < (upph ? 8 : 4))) return false;
     }
     if (did_res) *did_res = false;
-    if (NW == 4 && MW == 1 && !upph && res_out && wres && wres->Ask1x1 && wres->cout == w.cout && G == p.units && p.ndp == p.units) {
+    if (NW == 4 && MW == 1 && !upph && res_out && wres && wres->Ask1x1 && wres->cout == w.cout && ((G == p.units && p.ndp == p.units) || ksplit_on)) {
         // the block's 1x1 res_conv as the grid's last workgroups (one per (row tile, pixel tile)): same input, its own weights and output
         p.alt_units = p.rowtiles * p.ntiles; p.alt_A = wres->Ask1x1; p.alt_bias = wres->bias;
         p.alt_out = res_out->p; p.alt_out_ld = res_out->C;
         G += p.alt_units;
         if (did_res) *did_res = true;
     }
+    const int Gmain = G - p.alt_units;                               // the workgroups of the unit schedule (the finish kernel's view)
     p.partial = splitk_scratch();
     const size_t lds = L::lds_bytes(nhp);
     const int nsk = p.units - p.ndp;
     auto go = [&]() {
         if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 4>), dim3(G), dim3(L::THREADS), lds, st, p);
         else hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 9>), dim3(G), dim3(L::THREADS), lds, st, p);
-        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(NW, nsk), dim3(64), 0, st, p, G);
+        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(NW, nsk), dim3(64), 0, st, p, Gmain);
     };
 #ifdef UCDIR_TIMING
     {
