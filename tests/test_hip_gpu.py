@@ -110,8 +110,9 @@ def test_conv_persistent(args):
     (1, 144, 144, 64, 0, 128, 0, True, True, False, 0),     # the widest level this kernel takes in the network (halo of 806 positions; three strips of 48 for the 4-wave kind)
     (2, 50, 70, 64, 0, 128, 0, True, True, False, 0),       # two strips of 35 columns (4-wave kind), ragged in every direction
     (1, 40, 100, 64, 0, 256, 2, False, False, False, 0),    # Upsample on strips
+    (16, 36, 36, 512, 0, 512, 0, True, True, False, 0),     # the 36^2 level of the bench configuration
 ], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16",
-        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide", "strips_ragged", "strips_up"])
+        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide", "strips_ragged", "strips_up", "level3_b16"])
 @pytest.mark.parametrize("kind", [1, 2], ids=["persistent8", "oneshot4"])
 def test_conv_stream_k(args, kind):
     """conv_sk_kernel (persistent stream-K 3x3 conv / Upsample parity classes on 256-row x 256-position linear tiles) + its finish

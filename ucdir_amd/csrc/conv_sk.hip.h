@@ -129,7 +129,7 @@ __device__ __forceinline__ void lds_read8f_asm(f32x2_t& v, unsigned addr) {
 // or from partial tiles gives the same bits for the same accumulator values.
 template <int MW, int NW, int TAB, bool MS_ASM>
 __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[4][2],
-                                            int par, int rt, int tile, int wm, int wn, int lane, unsigned tab_base = 0) {
+                                            int par, int rt, int tile, int wm, int wn, int lane, unsigned tab_base = 0, int fsel = -1) {
     using L = CvSk<MW, NW>;
     const int hh = lane >> 5, l31 = lane & 31;
     const int act = p.act;
@@ -157,6 +157,7 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
+            if (fsel >= 0 && f != fsel) continue;                      // (finish kernel: one 32-row fragment per workgroup)
             const int ch = wm * 128 + f * 32 + 16 * hh;                // channel within the row tile
             const int fo = rt * L::ROWS + ch;
             f32x4_t b4[4], g4v[4];
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
 }
 
 // Second half of a stream-K launch: sums the partial tiles of every cut unit in ascending workgroup order (fixed: bit-reproducible)
-// and runs the epilogue.  grid = (8, stream-K units): one WAVE per workgroup, the slice of the unit that wave `blockIdx.x` of the conv
+// and runs the epilogue.  grid = (4 x waves, stream-K units): one WAVE per workgroup, one 32-row fragment of the slice of the unit that wave `blockIdx.x / 4` of the conv
 // kernel owns (many small workgroups: the pass is bound by reading the partial tiles, ~80 MB per launch); units that one
 // workgroup computed whole exit at once.
 template <int MW, int NW>
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
     __shared__ float ms[2 * L::MAXB];
     constexpr int NWN = L::NWN;
     const int lane = threadIdx.x;
-    const int wave = blockIdx.x;
+    const int wave = blockIdx.x >> 2, fsel = blockIdx.x & 3;         // one 32-row fragment (two MFMA tiles) of one wave's slice per workgroup
     const int wm = wave / NWN, wn = wave % NWN;
     const int nch = p.nchunks;
     const SkSched sch(p.units, p.ndp, nch, G);
@@ -768,7 +769,8 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         const bool first = sch.start(g) >= a;                        // this unit holds the workgroup's first chunk: its first segment
         const float* pr = p.partial + ((long long)(2 * g + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 4; ++f) {
+            if (f != fsel) continue;
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -777,8 +779,9 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
                     if (have) { acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w; }
                     else { acc[f][n][4 * g4] = v.x; acc[f][n][4 * g4 + 1] = v.y; acc[f][n][4 * g4 + 2] = v.z; acc[f][n][4 * g4 + 3] = v.w; }
                 }
+        }
         have = true;
     }
     __syncthreads();
-    sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane);
+    sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane, 0, fsel);
 }

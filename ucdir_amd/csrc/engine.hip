@@ -503,7 +503,7 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     auto go = [&]() {
         if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 4>), dim3(G), dim3(L::THREADS), lds, st, p);
         else hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 9>), dim3(G), dim3(L::THREADS), lds, st, p);
-        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(NW, nsk), dim3(64), 0, st, p, Gmain);
+        if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(4 * NW, nsk), dim3(64), 0, st, p, Gmain);
     };
 #ifdef UCDIR_TIMING
     {
