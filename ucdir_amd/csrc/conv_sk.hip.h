@@ -756,6 +756,23 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         if (p.npar > 1) { par = uu / per_par; uu -= par * per_par; }
         tile = uu / p.rowtiles; rt = uu - tile * p.rowtiles;
     }
+    // the first two parts (every cut unit has at least two) are requested BEFORE the per-sample scalars are built: the statistics loads,
+    // the fp64 mean / variance and the partial tiles are independent chains, the pass is latency-bound
+    const int fo = fsel * 2 * 4 * 256;                               // this workgroup's fragment inside a wave slice [f][n][reg / 4][lane][4]
+    auto part_ptr = [&](int gg) {
+        const bool first = sch.start(gg) >= a;                       // this unit holds the workgroup's first chunk: its first segment
+        return p.partial + ((long long)(2 * gg + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4 + fo;
+    };
+    float4 v0[2][4], v1[2][4];
+    const bool two = g + 1 < G && sch.start(g + 1) < b;
+    {
+        const float* p0 = part_ptr(g);
+        const float* p1 = part_ptr(two ? g + 1 : g);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) { v0[n][g4] = *reinterpret_cast<const float4*>(p0 + (n * 4 + g4) * 256); v1[n][g4] = *reinterpret_cast<const float4*>(p1 + (n * 4 + g4) * 256); }
+    }
     {
         const int per_b = p.ns * p.HpWpe;                            // the few samples this wave's 64 positions span
         const int q0 = tile * L::NPX + wn * 64;
@@ -764,10 +781,19 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         if (b0 < b1) sk_sample_table(p, ms + 2 * b0, b0, b1, 0, 1, lane);
     }
     f32x16_t acc[4][2];
-    bool have = false;
-    for (; g < G && sch.start(g) < b; ++g) {
-        const bool first = sch.start(g) >= a;                        // this unit holds the workgroup's first chunk: its first segment
-        const float* pr = p.partial + ((long long)(2 * g + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        if (f != fsel) continue;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                acc[f][n][4 * g4] = v0[n][g4].x; acc[f][n][4 * g4 + 1] = v0[n][g4].y; acc[f][n][4 * g4 + 2] = v0[n][g4].z; acc[f][n][4 * g4 + 3] = v0[n][g4].w;
+                if (two) { acc[f][n][4 * g4] += v1[n][g4].x; acc[f][n][4 * g4 + 1] += v1[n][g4].y; acc[f][n][4 * g4 + 2] += v1[n][g4].z; acc[f][n][4 * g4 + 3] += v1[n][g4].w; }
+            }
+    }
+    for (g += two ? 2 : 1; g < G && sch.start(g) < b; ++g) {          // further parts, in part order
+        const float* pr = part_ptr(g);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             if (f != fsel) continue;
@@ -775,12 +801,10 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 v = *reinterpret_cast<const float4*>(pr + ((f * 2 + n) * 4 + g4) * 256);
-                    if (have) { acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w; }
-                    else { acc[f][n][4 * g4] = v.x; acc[f][n][4 * g4 + 1] = v.y; acc[f][n][4 * g4 + 2] = v.z; acc[f][n][4 * g4 + 3] = v.w; }
+                    const float4 v = *reinterpret_cast<const float4*>(pr + (n * 4 + g4) * 256);
+                    acc[f][n][4 * g4] += v.x; acc[f][n][4 * g4 + 1] += v.y; acc[f][n][4 * g4 + 2] += v.z; acc[f][n][4 * g4 + 3] += v.w;
                 }
         }
-        have = true;
     }
     __syncthreads();
     sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane, 0, fsel);
