@@ -118,6 +118,12 @@ int32_t ucdir_sampler_step_rng(float* x_t, const float* eps, int64_t n,
                                float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
                                uint64_t seed, uint32_t step, void* stream);
 int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, void* stream);
+/* Window batch of the inter-step patch split (utils/util.py:113-137: F.pad(..., mode='reflect') then one slice per window) in ONE launch,
+ * straight from the un-padded canvas: out[(w * B + b)][c][y][x] = x[b][c][refl(h0_w + y - pad)][refl(w0_w + x - pad)], x (B, C, H, W) fp32,
+ * out (nwin * B, C, skip, skip) fp32, win_dev = nwin pairs (h0, w0) of int32 ON THE DEVICE in padded coordinates (the window list of
+ * utils/util.py:119-137).  Windows must lie inside the padded canvas (H + 2 pad) x (W + 2 pad); pad < H, W. */
+int32_t ucdir_gather_windows(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t pad, const int32_t* win_dev,
+                             int32_t nwin, int32_t skip, float* out, void* stream);
 
 /* ---- introspection (tests / profiling) ---------------------------------------------------
  * Copy the activation a layer produced in the last forward into dst as (B,C,Hc,Wc) fp32 NCHW

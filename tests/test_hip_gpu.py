@@ -680,3 +680,30 @@ def test_matrix_rate_probe_is_plausible():
     assert 800.0 < vals[0] <= vals[1] * 1.02 and vals[1] < 2600.0, vals
     v = ctypes.c_double(0.0)
     assert L.ucdir_matrix_rate(0, 1, ctypes.byref(v), C._st()) != 0        # bad argument: an error code, not a launch
+
+
+def test_gather_windows_matches_reflect_pad_and_slices():
+    """ucdir_gather_windows (one launch per engine call of the patch split) = F.pad(mode='reflect') + one slice per window
+    (utils/util.py:113-137), bit for bit, on a ragged canvas whose last windows are pulled back inside."""
+    import torch.nn.functional as F
+    from ucdir_amd import patch as P
+    from ucdir_amd.ucdir import gather_windows
+    g = C.rng(11)
+    x = torch.randn(2, 6, 150, 217, generator=g).cuda()
+    skip, padding = 96, 16
+    pd = P.patch_pad(150, 217, skip, padding)
+    xp = F.pad(x, (pd, pd, pd, pd), mode="reflect")
+    wins = P.patch_windows(xp.shape[-2], xp.shape[-1], skip, padding)
+    assert len(wins) >= 6
+    ref = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in wins], dim=0)
+    wd = torch.tensor([[a, c] for (a, b, c, d) in wins], dtype=torch.int32, device="cuda")
+    out = gather_windows(x, pd, wd, skip)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    # the pad of a canvas smaller than one window (pd > padding): reflect indexing far into the image
+    x2 = torch.randn(1, 6, 70, 90, generator=g).cuda()
+    pd2 = P.patch_pad(70, 90, skip, padding)
+    xp2 = F.pad(x2, (pd2, pd2, pd2, pd2), mode="reflect")
+    wins2 = P.patch_windows(xp2.shape[-2], xp2.shape[-1], skip, padding)
+    ref2 = torch.cat([xp2[..., a:b, c:d] for (a, b, c, d) in wins2], dim=0)
+    out2 = gather_windows(x2, pd2, torch.tensor([[a, c] for (a, b, c, d) in wins2], dtype=torch.int32, device="cuda"), skip)
+    assert torch.equal(out2, ref2)

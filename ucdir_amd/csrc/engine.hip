@@ -1629,6 +1629,24 @@ int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, voi
     API_END
 }
 
+int32_t ucdir_gather_windows(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t pad, const int32_t* win_dev, int32_t nwin,
+                             int32_t skip, float* out, void* stream) {
+    API_BEGIN
+    require(x && win_dev && out, "null argument");
+    require(B > 0 && C > 0 && H > 0 && W > 0 && nwin > 0 && skip > 0 && pad >= 0, "ucdir_gather_windows: bad shape");
+    require(pad < H && pad < W, "ucdir_gather_windows: reflect padding needs pad < H, W");
+    require((long long)nwin * B <= 65535 && C <= 65535, "ucdir_gather_windows: too many windows");
+    hipPointerAttribute_t pa;
+    HIPC(hipPointerGetAttributes(&pa, x));
+    require(pa.type == hipMemoryTypeDevice, "ucdir_gather_windows: x is not a device pointer");
+    DevGuard dg(pa.device);
+    const int xblocks = (skip + 255) / 256;
+    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)(xblocks * skip), (unsigned)C, (unsigned)(nwin * B)), dim3(256), 0, (hipStream_t)stream,
+                       x, B, C, H, W, pad, win_dev, skip, out);
+    HIPC(hipGetLastError());
+    API_END
+}
+
 int32_t ucdir_set_graph(ucdir_ctx* ctx, int32_t on) {
     API_BEGIN
     require(ctx, "null ctx");

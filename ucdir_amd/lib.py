@@ -41,6 +41,7 @@ _SIGS = {
     "ucdir_sampler_step_rng": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          ctypes.c_uint64, ctypes.c_uint32, c_void_p]),
     "ucdir_fill_normal": (c_int32, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint32, c_void_p]),
+    "ucdir_gather_windows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "ucdir_sampler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                      c_float, c_void_p]),
     "ucdir_debug_read": (c_int32, [c_void_p, c_char_p, c_char_p, c_void_p, c_int64, c_void_p]),

@@ -60,8 +60,17 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
         cache = {}
     B = noisy.shape[0]
     pd = patch_pad(noisy.shape[-2], noisy.shape[-1], skip, padding)
-    xp = F.pad(noisy, (pd, pd, pd, pd), mode="reflect")
-    _, _, H, W = xp.shape
+    # on the device the window batches are gathered straight from the un-padded canvas by one kernel per engine call
+    # (ucdir_gather_windows: reflect indexing in the kernel, no padded copy, no per-window cat); CPU tensors (the gloo tests'
+    # stub engines) take the reference's own route, F.pad + slices
+    on_dev = noisy.is_cuda and noisy.dtype == torch.float32
+    if on_dev:
+        noisy = noisy.contiguous()
+        xp = noisy
+        H, W = noisy.shape[-2] + 2 * pd, noisy.shape[-1] + 2 * pd
+    else:
+        xp = F.pad(noisy, (pd, pd, pd, pd), mode="reflect")
+        _, _, H, W = xp.shape
     wins = patch_windows(H, W, skip, padding)
     rank, world = 0, 1
     if group is not None:
@@ -82,7 +91,16 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
             chunks.append(chunk + [chunk[-1]] * (size - len(chunk)))
         gbs = _guide_chunks(params["guide"], pd, chunks, cache)
         for chunk, real, gb in zip(chunks, reals, gbs):
-            xb = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
+            if on_dev:
+                from .ucdir import gather_windows
+                wkey = ("win", tuple(chunk), noisy.device)
+                wd = cache.get(wkey)
+                if wd is None:                                       # (h0, w0) of the chunk's windows on the device: once per restoration
+                    wd = torch.tensor([[a, c] for (a, b, c, d) in chunk], dtype=torch.int32, device=noisy.device)
+                    cache[wkey] = wd
+                xb = gather_windows(noisy, pd, wd, skip)
+            else:
+                xb = torch.cat([xp[..., a:b, c:d] for (a, b, c, d) in chunk], dim=0).contiguous()
             tb = params["time"].repeat(len(chunk), 1)
             o = net(xb, tb, gb)
             outs.append(o[:real * B, :, padding:-padding, padding:-padding])

@@ -326,6 +326,20 @@ def sampler_step_rng_(x_t, eps, seed, step, c_recip, c_recipm1, coef1, coef2, si
     return x_t
 
 
+def gather_windows(x, pad, win_dev, skip):
+    """Window batch of the inter-step patch split in one launch (utils/util.py:113-137: reflect pad + one slice per window):
+    x (B, C, H, W) fp32 CUDA, win_dev (nwin, 2) int32 CUDA = (h0, w0) in padded coordinates -> (nwin * B, C, skip, skip)."""
+    L = _lib.load()
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and win_dev.is_cuda and win_dev.dtype == torch.int32
+            and win_dev.is_contiguous() and win_dev.dim() == 2 and win_dev.shape[1] == 2):
+        raise _lib.UcdirError("gather_windows needs a contiguous fp32 CUDA canvas and an (nwin, 2) int32 CUDA window list")
+    B, C, H, W = x.shape
+    nwin = win_dev.shape[0]
+    out = torch.empty((nwin * B, C, skip, skip), dtype=torch.float32, device=x.device)
+    _lib.check(L.ucdir_gather_windows(_ptr(x), B, C, H, W, int(pad), _ptr(win_dev), nwin, int(skip), _ptr(out), _stream_ptr(x.device)))
+    return out
+
+
 def fill_normal_(x, seed, step=0):
     """x <- N(0, 1) from the sampler's counter-based generator (x_T = step 0 of the stream the update kernel draws from)."""
     L = _lib.load()
