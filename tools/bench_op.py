@@ -3,7 +3,7 @@
   python tools/bench_op.py akgm B H W C [reps]
   python tools/bench_op.py attn B C H W [reps]
 """
-import ctypes, math, os, sys, time
+import os, ctypes, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
@@ -11,6 +11,8 @@ import hip_checks as C
 from ucdir_amd import lib as ulib
 L = ulib.load()
 kind = sys.argv[1]
+if os.environ.get("BENCH_CONVSK"):      # force a conv_sk kind (ucdir_debug_flag("convsk", n)) regardless of the size thresholds
+    ulib.check(L.ucdir_debug_flag(b"convsk", int(os.environ["BENCH_CONVSK"])))
 if kind == "conv":
     B, H, W, cin, cout = map(int, sys.argv[2:7]); reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
     g = C.rng(0)
