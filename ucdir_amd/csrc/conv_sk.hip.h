@@ -134,6 +134,8 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
     const int hh = lane >> 5, l31 = lane & 31;
     const int act = p.act;
     const int py = par >> 1, pxp = par & 1;
+    int sb_n[2] = {0, 0};
+    stat_t sf1[2] = {0, 0}, sf2[2] = {0, 0};
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int q = tile * L::NPX + wn * 64 + n * 32 + l31;          // position in [B][strip][H + 2][Ws + 2]
@@ -238,15 +240,18 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
                 *reinterpret_cast<uint4*>(op + 8) = pack8_bf16(v + 8);
             }
         }
-        if (p.stats_out) {
-            // per-sample sums: the 32 positions of this MFMA tile usually belong to one sample; loop over the few they can span
-            const int b_lo = __builtin_amdgcn_readlane(b, 0), b_hi0 = __builtin_amdgcn_readlane(b, 31);
-            const int b_hi = b_hi0 < p.nb ? b_hi0 : p.nb - 1;
-            const stat_t f1 = valid ? stat_fx((double)s1) : 0, f2 = valid ? stat_fx((double)s2) : 0;
-            for (int sb = b_lo; sb <= b_hi; ++sb) {
-                const stat_t a = wave_sum_ll(b == sb ? f1 : 0), q2 = wave_sum_ll(b == sb ? f2 : 0);
-                if (lane == 0 && (a != 0 || q2 != 0)) stat_add_fx(p.stats_out, sb, a, q2);
-            }
+        if (p.stats_out) { sb_n[n] = b; sf1[n] = valid ? stat_fx((double)s1) : 0; sf2[n] = valid ? stat_fx((double)s2) : 0; }
+    }
+    if (p.stats_out) {
+        // per-sample sums of the wave's 64 positions (both MFMA tiles in ONE pair of wave reductions: the 64-bit shuffles are a dependent
+        // chain of ~700 cycles each): they usually belong to one sample; loop over the few they can span.  Integer sums: any grouping
+        // gives the same bits.
+        const int b_lo = __builtin_amdgcn_readlane(sb_n[0], 0), b_hi0 = __builtin_amdgcn_readlane(sb_n[1], 31);
+        const int b_hi = b_hi0 < p.nb ? b_hi0 : p.nb - 1;
+        for (int sb = b_lo; sb <= b_hi; ++sb) {
+            const stat_t a = wave_sum_ll((sb_n[0] == sb ? sf1[0] : 0) + (sb_n[1] == sb ? sf1[1] : 0));
+            const stat_t q2 = wave_sum_ll((sb_n[0] == sb ? sf2[0] : 0) + (sb_n[1] == sb ? sf2[1] : 0));
+            if (lane == 0 && (a != 0 || q2 != 0)) stat_add_fx(p.stats_out, sb, a, q2);
         }
     }
 }
