@@ -38,6 +38,7 @@ struct ConvSkP {
     // position space: [sample][strip][H + 2][Ws + 2] - the image is cut into ns vertical strips of Ws columns, each carried with its
     // two neighbour columns (ns = 1: the zero-bordered tensor itself); npos = nb * ns * HpWpe positions, tiles are NPX consecutive ones
     int ns, Ws, Wpe, HpWpe, npos;
+    float inv_per_b, inv_HpWpe, inv_Wpe;               // reciprocals for sk_udiv (1 / (ns * HpWpe), 1 / HpWpe, 1 / Wpe)
     int ntiles, rowtiles, npar;                       // pixel tiles, row tiles, parity classes (1 | 4); units = npar * rowtiles * ntiles
     int nhp;                                          // halo DMA pieces (16 positions each) per chunk
     int nfeat;
@@ -107,13 +108,22 @@ struct SkSched {
 
 // position q of the strip space -> sample, padded row, column inside the strip (0 and Ws + 1: the neighbour columns) and padded column
 // of the tensor
+// Exact q / d for 0 <= q < 2^31 and quotients below 2^22 (samples, strips, rows): the float product is within one of the quotient, two
+// integer fix-ups make it exact - ~10 instructions instead of the ~35 of a 32-bit integer division (eight decodes of three divisions per unit
+// were ~3 k cycles of a unit's prologue and epilogue)
+__device__ __forceinline__ int sk_udiv(int q, int d, float inv_d) {
+    int t = (int)((float)q * inv_d);
+    t = t * d > q ? t - 1 : t;
+    t = (t + 1) * d <= q ? t + 1 : t;
+    return t;
+}
 __device__ __forceinline__ void sk_decode(const ConvSkP& p, int q, int& b, int& yp, int& xs, int& xpm) {
     const int per_b = p.ns * p.HpWpe;
-    b = q / per_b;
+    b = sk_udiv(q, per_b, p.inv_per_b);
     int r = q - b * per_b;
     int strip = 0;
-    if (p.ns > 1) { strip = r / p.HpWpe; r -= strip * p.HpWpe; }
-    yp = r / p.Wpe; xs = r - yp * p.Wpe;
+    if (p.ns > 1) { strip = sk_udiv(r, p.HpWpe, p.inv_HpWpe); r -= strip * p.HpWpe; }
+    yp = sk_udiv(r, p.Wpe, p.inv_Wpe); xs = r - yp * p.Wpe;
     xpm = strip * p.Ws + xs;
 }
 
@@ -121,6 +131,28 @@ __device__ __forceinline__ void sk_decode(const ConvSkP& p, int q, int& b, int& 
 // wait for them: hipcc puts vmcnt(0) in front of every LDS read it knows about while an LDS-DMA is outstanding)
 __device__ __forceinline__ void lds_read8f_asm(f32x2_t& v, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+}
+
+// 64-bit wave sum on the DPP network instead of six dependent ds_bpermute pairs (~700 cycles each in the epilogue): prefix sums inside
+// the rows of 16 (row_shr 1 / 2 / 4 / 8), row totals into the odd rows (row_bcast:15, rows 1 and 3), the lower half's total into the
+// upper half (row_bcast:31, rows 2 and 3); lane 63 holds the wave's sum.  Integer adds: same bits as any other order.
+__device__ __forceinline__ stat_t wave_sum_ll_dpp(stat_t v) {
+    auto step = [&](auto ctrl, auto rmask) {
+        constexpr int C = decltype(ctrl)::value, RM = decltype(rmask)::value;
+        const unsigned lo = (unsigned)(v & 0xffffffffll), hi = (unsigned)((unsigned long long)v >> 32);
+        const unsigned tlo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, C, RM, 0xf, true);
+        const unsigned thi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, C, RM, 0xf, true);
+        v += (stat_t)(((unsigned long long)thi << 32) | tlo);
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), 63);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), 63);
+    return (stat_t)(((unsigned long long)rhi << 32) | rlo);
 }
 
 // epilogue of one wave's 128 x 64 tile from its accumulators: GroupNorm fold, activation, residual, statistics, bf16 NHWC store.
@@ -249,8 +281,8 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
         const int b_lo = __builtin_amdgcn_readlane(sb_n[0], 0), b_hi0 = __builtin_amdgcn_readlane(sb_n[1], 31);
         const int b_hi = b_hi0 < p.nb ? b_hi0 : p.nb - 1;
         for (int sb = b_lo; sb <= b_hi; ++sb) {
-            const stat_t a = wave_sum_ll((sb_n[0] == sb ? sf1[0] : 0) + (sb_n[1] == sb ? sf1[1] : 0));
-            const stat_t q2 = wave_sum_ll((sb_n[0] == sb ? sf2[0] : 0) + (sb_n[1] == sb ? sf2[1] : 0));
+            const stat_t a = wave_sum_ll_dpp((sb_n[0] == sb ? sf1[0] : 0) + (sb_n[1] == sb ? sf1[1] : 0));
+            const stat_t q2 = wave_sum_ll_dpp((sb_n[0] == sb ? sf2[0] : 0) + (sb_n[1] == sb ? sf2[1] : 0));
             if (lane == 0 && (a != 0 || q2 != 0)) stat_add_fx(p.stats_out, sb, a, q2);
         }
     }
@@ -553,8 +585,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     // (alpha * rstd, mean * rstd): persistent workgroups build the whole list once, one-shot ones the few samples their tile spans
     auto sample_range = [&](const Seg& s) {
         const int per_b = p.ns * p.HpWpe;
-        const int b0 = (s.tile * L::NPX) / per_b;
-        int b1 = (s.tile * L::NPX + L::NPX - 1) / per_b + 1; b1 = b1 < p.nb ? b1 : p.nb;
+        const int b0 = sk_udiv(s.tile * L::NPX, per_b, p.inv_per_b);
+        int b1 = sk_udiv(s.tile * L::NPX + L::NPX - 1, per_b, p.inv_per_b) + 1; b1 = b1 < p.nb ? b1 : p.nb;
         if (b0 < b1) sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS) + 2 * b0, b0, b1, wave, NW, lane);
     };
     if (L::LDS_TAB) {
@@ -781,8 +813,8 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
     {
         const int per_b = p.ns * p.HpWpe;                            // the few samples this wave's 64 positions span
         const int q0 = tile * L::NPX + wn * 64;
-        const int b0 = q0 / per_b;
-        int b1 = (q0 + 63) / per_b + 1; b1 = b1 < p.nb ? b1 : p.nb;
+        const int b0 = sk_udiv(q0, per_b, p.inv_per_b);
+        int b1 = sk_udiv(q0 + 63, per_b, p.inv_per_b) + 1; b1 = b1 < p.nb ? b1 : p.nb;
         if (b0 < b1) sk_sample_table(p, ms + 2 * b0, b0, b1, 0, 1, lane);
     }
     f32x16_t acc[4][2];

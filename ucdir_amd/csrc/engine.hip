@@ -451,6 +451,7 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     p.nchunks = cin / 32;
     p.nb = B; p.H = H; p.W = W; p.Wp = Wp; p.Hp = Hp;
     p.ns = ns; p.Ws = Ws; p.Wpe = Wpe; p.HpWpe = HpWpe; p.npos = (int)npos;
+    p.inv_per_b = 1.0f / (float)(ns * HpWpe); p.inv_HpWpe = 1.0f / (float)HpWpe; p.inv_Wpe = 1.0f / (float)Wpe;
     p.ntiles = (int)((npos + NPX - 1) / NPX); p.rowtiles = (w.cout + L::ROWS - 1) / L::ROWS; p.npar = upph ? 4 : 1;
     p.nhp = nhp; p.nfeat = w.cout;
     p.alpha = 1.f; p.fold = (!upph && w.fold) ? 1 : 0; p.act = act;
