@@ -1762,8 +1762,8 @@ int32_t ucdir_matrix_rate(int32_t iters, int32_t random, double* tflops, void* s
     API_BEGIN
     if (iters <= 0 || !tflops) throw std::runtime_error("ucdir_matrix_rate: iters > 0 and a result pointer are required");
     hipStream_t st = (hipStream_t)stream;
-    static float* sink = nullptr;
-    if (!sink) HIPC(hipMalloc((void**)&sink, 4));
+    float* sink = nullptr;                                           // (per call, on the current device: a probe, not a hot path)
+    HIPC(hipMalloc((void**)&sink, 4));
     hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     const int grid = 2 * num_cus();
     float best = 1e30f;
@@ -1775,6 +1775,7 @@ int32_t ucdir_matrix_rate(int32_t iters, int32_t random, double* tflops, void* s
         if (r && ms < best) best = ms;
     }
     HIPC(hipEventDestroy(e0)); HIPC(hipEventDestroy(e1));
+    HIPC(hipFree(sink));
     *tflops = 2.0 * 32 * 32 * 16 * 8.0 * iters * 4 * grid / (best * 1e-3) / 1e12;
     API_END
 }
