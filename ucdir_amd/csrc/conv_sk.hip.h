@@ -25,6 +25,12 @@
 //   * epilogue in registers: rows are permuted at pack time so that a lane holds 16 consecutive channels of one pixel per MFMA tile
 //     (32-byte pieces); GroupNorm fold from two sample-independent tables in LDS (bias + Tb, Tg; 9 border classes) and the
 //     per-sample (rstd, mean * rstd) list built once per workgroup; output statistics as 2^-20 fixed-point integers.
+// What ships as the default (measured): the SAME wave tile and loop in 4-wave workgroups of 128 rows x 256 positions with
+// 80 KB of LDS, two per CU, one unit each (template <1, 4, NTAPS>): one's prologue / epilogue runs under the other's K loop, the fold tables
+// arrive by LDS-DMA under the last chunk, the block's 1x1 res_conv rides as the grid's last workgroups (sk_alt_unit), wide images are cut
+// into vertical strips.  Launches with few long units (the 18^2 level at B = 16) cut every unit's K range in two; the partial tiles are
+// summed in part order by conv_sk_finish_kernel (one wave per 32-row fragment).  The 8-wave persistent stream-K kind above is the tested
+// alternative (ucdir_debug_flag("convsk", 1)).
 // Reference: model/ucdir.py:110 (block conv1), :57 (Upsample conv), SURVEY.md Appendix A.
 #pragma once
 #include "conv_halo.hip.h"
