@@ -19,6 +19,25 @@ cases = [
     ("attn512", lambda: C.attention_case(3, 512, 18, 18, seed=7, flash=1), 0),
     ("attn256", lambda: C.attention_case(3, 256, 20, 24, seed=8, flash=1), 0),
 ]
+# conv_sk (round 4): counted vmcnt / lgkmcnt, LDS-DMA ring, the K cut + finish pass, res_conv workgroups, Upsample classes, stream-K remainder
+def _sk(kind, fn):
+    def run():
+        C.ulib.check(L.ucdir_debug_flag(b"convsk", kind))
+        try:
+            return fn()
+        finally:
+            C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
+    return run
+
+
+cases += [
+    ("sk_level4_ksplit", _sk(2, lambda: C.conv_case(16, 18, 18, 512, 512, 512, 3, 0, True, True, False, seed=5)), 0),
+    ("sk_level3", _sk(2, lambda: C.conv_case(16, 36, 36, 512, 0, 512, 3, 0, True, True, False, seed=5)), 0),
+    ("sk_res", _sk(2, lambda: C.conv_res_case(3, 18, 18, 512, 256, 512, seed=7)), 0),
+    ("sk_up", _sk(2, lambda: C.conv_case(2, 16, 24, 128, 0, 256, 3, 2, False, False, False, seed=5)), 0),
+    ("sk_streamk_7wg", _sk(2, lambda: C.conv_case(2, 36, 36, 256, 0, 512, 3, 0, True, True, True, seed=5)), 7),
+    ("sk8_streamk", _sk(1, lambda: C.conv_case(5, 10, 12, 64, 0, 256, 3, 0, True, False, False, seed=5)), 3),
+]
 bad = 0
 for name, fn, grid in cases:
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
@@ -26,7 +45,7 @@ for name, fn, grid in cases:
         first = None
         for r in range(reps):
             m = fn()
-            key = (m["max_abs"], m["rel_rms"], str(m.get("stats")))
+            key = (m["max_abs"], m["rel_rms"], str(m.get("stats")), str(m.get("stats_rel")), str(m.get("res_rel_rms")))
             if first is None:
                 first = key
                 assert not m["nan"] and m.get("rel_rms_branch", m["rel_rms"]) < 1.2e-2, (name, m)
