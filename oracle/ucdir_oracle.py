@@ -222,6 +222,147 @@ def dy3h_naive_forward(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torc
     return F.conv2d(swish(h), sd[prefix + "final_conv.3.weight"], sd[prefix + "final_conv.3.bias"], padding=1)
 
 
+# ----------------------------------------------------------------------------------------------
+# bf16 numerics emulation of the HIP engine (second oracle mode)
+# ----------------------------------------------------------------------------------------------
+# The HIP path computes with bf16 operands, fp32 accumulation and bf16 activations.  Against the fp32 restatement above a full
+# SID forward therefore differs by ~1.5e-2 rel-RMS of pure rounding noise, and a bound that wide cannot see a systematic error
+# below ~1e-2.  This mode restates the SAME network (model/ucdir.py:122-140, 165-182, 270-293) with a round-to-nearest-even bf16
+# cast at exactly the points where the kernels round (ucdir_amd/csrc: pack.h for the weights, the epilogues for the activations):
+#   * every activation tensor is stored as bf16; GroupNorm statistics are taken from the fp32 values BEFORE that rounding;
+#   * conv(GroupNorm(x)) is evaluated as the kernels do: rstd * conv_{bf16(W gamma)}(x_bf16) + bias + conv_W(beta) - mean * rstd *
+#     conv_{bf16(W gamma)}(1) with zero padding inside the two table terms (the nine border classes of pack_conv);
+#   * Upsample + conv3x3 as four parity classes of 2x2 convs with pre-summed weights rounded once (pack_upconv);
+#   * attention: q, k, v' = (W_o W_v) GN(x) as bf16 (fold_out_into_v, engine.hip), probabilities rounded to bf16 before P V',
+#     the row sum from the unrounded ones; the stem's inputs and the final conv's activated input rounded to bf16;
+#   * time MLP, guide branch and modulation weights stay fp32 (time_mlp_kernel, guide_branch_kernel).
+# With ``rnd=False`` the casts are identities and the function is an algebraic re-arrangement of dy3h_naive_forward: that is
+# how it is pinned (tests/test_oracle_golden.py compares the two, and dy3h_naive_forward is pinned by the reference's fixtures).
+def _rb(x: torch.Tensor, rnd: bool = True) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32) if rnd else x
+
+
+def _mean_rstd(srcs: Sequence[torch.Tensor]):
+    """Per-sample GroupNorm(1 group) mean / rstd over the channel concatenation of ``srcs`` (fp32 values before rounding)."""
+    n = sum(t[0].numel() for t in srcs)
+    s1 = sum(t.double().sum(dim=(1, 2, 3)) for t in srcs)
+    s2 = sum(t.double().pow(2).sum(dim=(1, 2, 3)) for t in srcs)
+    mean = s1 / n
+    var = (s2 / n - mean * mean).clamp(min=0)
+    return mean.float().view(-1, 1, 1, 1), (1.0 / torch.sqrt(var + 1e-5)).float().view(-1, 1, 1, 1)
+
+
+def _fold_conv(xb, mean, rstd, w, bias, gamma, beta, rnd, groups=1):
+    """conv3x3 / conv1x1 (zero padding) of GroupNorm(x) with the affine folded into the weights, as the epilogues evaluate it."""
+    k = w.shape[-1]
+    cin = xb.shape[1]
+    gsel = gamma.view(groups, 1, cin // groups, 1, 1).expand(groups, w.shape[0] // groups, cin // groups, 1, 1).reshape(w.shape[0], cin // groups, 1, 1)
+    wq = _rb(w * gsel, rnd)
+    H, W = xb.shape[-2:]
+    acc = F.conv2d(xb, wq, padding=k // 2, groups=groups)
+    tg = F.conv2d(torch.ones(1, cin, H, W, dtype=xb.dtype), wq, padding=k // 2, groups=groups)
+    tb = F.conv2d(beta.view(1, cin, 1, 1).expand(1, cin, H, W).contiguous(), w, padding=k // 2, groups=groups)
+    out = rstd * acc + tb - mean * rstd * tg
+    return out if bias is None else out + bias.view(1, -1, 1, 1)
+
+
+def resblock_dy3h_emu(sd: SD, p: str, srcs: Sequence[torch.Tensor], temb: torch.Tensor, guide: torch.Tensor, rnd: bool,
+                      taps: Optional[dict] = None) -> torch.Tensor:
+    """ResnetBlockDY3h.forward (model/ucdir.py:122-140) with the engine's rounding points.  ``srcs``: the fp32 (pre-rounding)
+    tensors whose channel concatenation is the block's input.  Returns the fp32 value the engine rounds on store."""
+    B, _, H, W = srcs[0].shape
+    xb = torch.cat([_rb(t, rnd) for t in srcs], dim=1)
+    attw = time_weights(sd, p, temb)
+    mean, rstd = _mean_rstd(srcs)
+    h1 = swish(_fold_conv(xb, mean, rstd, sd[p + "conv1.weight"], sd[p + "conv1.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"], rnd))
+    if taps is not None:
+        taps[p + "h1"] = h1
+    m2, r2 = _mean_rstd([h1])
+    att_sp = guide_branch(sd, p, guide, W) * attw.view(B, -1, 1, 1)
+    nset = att_sp.shape[1]
+    hset = _fold_conv(_rb(h1, rnd), m2, r2, sd[p + "spdyconv.weight"], sd[p + "spdyconv.bias"], sd[p + "norm2.weight"],
+                      sd[p + "norm2.bias"], rnd, groups=nset)
+    cout = hset.shape[1] // nset
+    h = swish((hset.view(B, cout, nset, H, W) * att_sp.unsqueeze(1)).sum(dim=2))
+    if (p + "res_conv.weight") in sd:
+        res = _rb(F.conv2d(xb, _rb(sd[p + "res_conv.weight"], rnd), sd[p + "res_conv.bias"]), rnd)
+    else:
+        res = xb
+    return h + res
+
+
+def self_attention_emu(sd: SD, p: str, x32: torch.Tensor, rnd: bool) -> torch.Tensor:
+    """SelfAttention.forward (model/ucdir.py:165-182) as the engine evaluates it: the out projection folded into the value rows
+    (fp64 product, one rounding), q / k / v' and the probabilities as bf16, fp32 accumulation."""
+    B, C, H, W = x32.shape
+    xb = _rb(x32, rnd)
+    mean, rstd = _mean_rstd([x32])
+    wqkv = sd[p + "qkv.weight"].reshape(3 * C, C)
+    wv2 = (sd[p + "out.weight"].reshape(C, C).double() @ wqkv[2 * C:].double()).float()
+    wf = torch.cat([wqkv[:2 * C], wv2]).reshape(3 * C, C, 1, 1)
+    qkv = _rb(_fold_conv(xb, mean, rstd, wf, None, sd[p + "norm.weight"], sd[p + "norm.bias"], rnd), rnd)
+    q, k, v = qkv.reshape(B, 3, C, H * W).unbind(dim=1)
+    s = torch.bmm(q.transpose(1, 2), k) / math.sqrt(C)
+    pr = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+    out = torch.bmm(v, _rb(pr, rnd).transpose(1, 2)) / pr.sum(dim=-1).unsqueeze(1)
+    return out.reshape(B, C, H, W) + sd[p + "out.bias"].view(1, -1, 1, 1) + xb
+
+
+def _upconv_emu(xb: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, rnd: bool) -> torch.Tensor:
+    """Upsample (nearest x2) + conv3x3 (model/ucdir.py:53-60) as four parity classes of 2x2 convs on the low-res grid."""
+    B, _, H, W = xb.shape
+    xp = F.pad(xb, (1, 1, 1, 1))
+    sel = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # parity -> taps of (d = 0, d = 1)
+    out = torch.empty(B, w.shape[0], 2 * H, 2 * W, dtype=xb.dtype)
+    for py in range(2):
+        for px in range(2):
+            w2 = torch.stack([torch.stack([w[:, :, sel[py][dy], :][:, :, :, sel[px][dx]].double().sum(dim=(2, 3)) for dx in range(2)], dim=-1)
+                              for dy in range(2)], dim=-2).float()
+            out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + H + 1, px:px + W + 1], _rb(w2, rnd))
+    return out + bias.view(1, -1, 1, 1)
+
+
+def dy3h_naive_forward_emu(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torch.Tensor, prefix: str = "denoise_fn.",
+                           taps: Optional[dict] = None, rnd: bool = True) -> torch.Tensor:
+    """DY3h.naiveforward (model/ucdir.py:270-293) with bf16 rounding where ucdir_amd/csrc rounds (``rnd=False``: no rounding,
+    equal to dy3h_naive_forward up to fp32 re-association)."""
+    temb = noise_embedding(sd, level, prefix)
+    downs, mid, ups = _layer_plan(sd, prefix)
+    feats = []
+
+    def run_block(base, srcs):
+        y = resblock_dy3h_emu(sd, base + "res_block.", srcs, temb, guide, rnd, taps)
+        if (base + "attn.qkv.weight") in sd:
+            y = self_attention_emu(sd, base + "attn.", y, rnd)
+        if taps is not None:
+            taps[base[:-1]] = y
+        return y
+
+    for kind, base in downs:
+        if kind == "stem":
+            x = F.conv2d(_rb(x, rnd), _rb(sd[base + "weight"], rnd), sd[base + "bias"], padding=1)
+        elif kind == "resample":
+            x = F.conv2d(_rb(x, rnd), _rb(sd[base + "conv.weight"], rnd), sd[base + "conv.bias"], stride=2, padding=1)
+        else:
+            x = run_block(base, [x])
+        if taps is not None and kind != "block":
+            taps[base[:-1]] = x
+        feats.append(x)
+    for kind, base in mid:
+        x = run_block(base, [x])
+    for kind, base in ups:
+        if kind == "resample":
+            x = _upconv_emu(_rb(x, rnd), sd[base + "conv.weight"], sd[base + "conv.bias"], rnd)
+            if taps is not None:
+                taps[base[:-1]] = x
+        else:
+            x = run_block(base, [x, feats.pop()])
+    mean, rstd = _mean_rstd([x])
+    g, b = sd[prefix + "final_conv.0.weight"].view(1, -1, 1, 1), sd[prefix + "final_conv.0.bias"].view(1, -1, 1, 1)
+    h = _rb(swish((_rb(x, rnd) - mean) * rstd * g + b), rnd)
+    return F.conv2d(h, _rb(sd[prefix + "final_conv.3.weight"], rnd), sd[prefix + "final_conv.3.bias"], padding=1)
+
+
 def pad32(n: int) -> int:
     return (n // 32 + 1) * 32 - n      # model/ucdir.py:303-304 (always 1..32)
 
@@ -258,16 +399,17 @@ def patch_forward_guide(x: torch.Tensor, net, level, guide, skip: int, padding: 
 
 def dy3h_forward(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torch.Tensor,
                  prefix: str = "denoise_fn.", patch_threshold: int = 1024 * 1024,
-                 skip: int = 1024, padding: int = 64) -> torch.Tensor:
-    """DY3h.forward (model/ucdir.py:295-307)."""
+                 skip: int = 1024, padding: int = 64, emulate_bf16: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
+    """DY3h.forward (model/ucdir.py:295-307).  ``emulate_bf16``: the engine's numerics plan (dy3h_naive_forward_emu)."""
+    naive = dy3h_naive_forward_emu if emulate_bf16 else dy3h_naive_forward
     _, _, h, w = x.shape
     if h * w > patch_threshold:
-        net = lambda xx, ll, gg: dy3h_naive_forward(sd, xx, ll, gg, prefix)
+        net = lambda xx, ll, gg: naive(sd, xx, ll, gg, prefix)
         return patch_forward_guide(x, net, level, guide, skip, padding)
     ph, pw = pad32(h), pad32(w)
     xp = F.pad(x, (0, pw, 0, ph), mode="reflect")
     gp = F.pad(guide, (0, pw, 0, ph), mode="reflect")
-    return dy3h_naive_forward(sd, xp, level, gp, prefix)[..., :-ph, :-pw]
+    return naive(sd, xp, level, gp, prefix, taps)[..., :-ph, :-pw]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -200,19 +200,26 @@ def test_akgm(Cc):
     (3, 256, 32, 48, 4096),  # 32 channels per group (akgm_ws32_kernel): one group per workgroup, 32 x 8 tiles, one tile per workgroup
     (2, 256, 48, 40, 16),    # ... 24 x 8 tiles, ranges of 10 tiles that cross the sample boundary (two workgroups per group)
     (5, 256, 72, 72, 0),     # ... the network's 72^2 level on one workgroup per CU
+    (2, 512, 20, 24, 16),    # 64 channels per group (akgm_ws64_kernel): one half group per workgroup, linear tiles of 128 positions, one range per role that crosses the sample
+    (3, 512, 18, 18, 32),    # ... two ranges of 4-5 tiles per role that cross sample boundaries
+    (2, 512, 12, 60, 48),    # ... a wide plane: the halo of a 128-position tile at its LDS limit (254 of 272 positions), three ranges per role
+    (6, 512, 36, 36, 0),     # ... the network's 36^2 level on one workgroup per CU (128-position tiles)
+    (8, 512, 18, 18, 0),     # ... the network's 18^2 level (64-position tiles: fewer than four 128-position tiles per range)
 ], ids=["even_small", "ranges_cross_samples", "ragged_ranges", "level0", "cg16_small", "cg16_ranges", "cg16_level1",
-        "cg32_small", "cg32_ranges", "cg32_level2"])
+        "cg32_small", "cg32_ranges", "cg32_level2", "cg64_small", "cg64_ranges", "cg64_wide", "cg64_level3", "cg64_level4"])
 def test_akgm_persistent(args):
-    """akgm_ws_kernel / akgm_ws32_kernel (8 | 16 | 32 channels per group, persistent, weight-stationary): tile ranges, sample
-    crossings, border classes."""
+    """akgm_ws_kernel / akgm_ws32_kernel / akgm_ws64_kernel (8 | 16 | 32 | 64 channels per group, persistent, weight-stationary):
+    tile ranges, sample crossings, border classes; the profiler's key proves which kernel ran."""
     B, Cc, H, W, grid = args
     L = C.ulib.load()
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
     try:
-        m = C.akgm_case(B, Cc, H, W, seed=5)
+        m, keys = _profile_keys(L, lambda: C.akgm_case(B, Cc, H, W, seed=5))
         m2 = C.akgm_case(B, Cc, H, W, seed=5)
     finally:
         C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
+    if Cc == 512:
+        assert 116 in keys, keys
     assert not m["nan"] and m["rel_rms"] < OP_TOL, m
     assert m["max_abs_border"] < 0.06, m
     assert m["stats_rel"] < 1e-3, m                                      # GroupNorm partial sums of the output
@@ -446,7 +453,7 @@ def test_forward_bench_dispatch_vs_oracle_and_reference(golden_dir, sid_net, B):
         torch.cuda.synchronize()
         return e.cpu()
     eps, keys = _profile_keys(L, fwd)
-    want = [113, 114, 115, 23, 24, 105]
+    want = [113, 114, 115, 116, 23, 24, 105]
     assert all(k in keys for k in want), (sorted(keys), want)
     assert bool(torch.isfinite(eps).all())
     for b in (0, B - 1):
@@ -650,7 +657,7 @@ def test_persistent_kernel_switches_agree_at_a_size_where_they_engage():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    off = {k: "1" for k in ("UCDIR_NO_WS", "UCDIR_NO_WS16", "UCDIR_NO_WS32", "UCDIR_NO_CONV_WS", "UCDIR_NO_CONV_WS128",
+    off = {k: "1" for k in ("UCDIR_NO_WS", "UCDIR_NO_WS16", "UCDIR_NO_WS32", "UCDIR_NO_WS64", "UCDIR_NO_CONV_WS", "UCDIR_NO_CONV_WS128",
                             "UCDIR_NO_QKV_WS", "UCDIR_NO_ATILE", "UCDIR_NO_CONV_SK")}
     out = {}
     for tag, env_extra in (("default", {}), ("oneshot", off)):
@@ -665,7 +672,7 @@ def test_persistent_kernel_switches_agree_at_a_size_where_they_engage():
         for b in ("s0", "s3"):
             assert not m[b]["nan"] and m[b]["rel_rms"] < FWD_TOL, (tag, b, m[b])
     assert 113 in out["default"]["keys"] and 23 in out["default"]["keys"] and 24 in out["default"]["keys"], out["default"]["keys"]
-    assert not any(k in out["oneshot"]["keys"] for k in (113, 114, 115, 23, 24, 105, 125)), out["oneshot"]["keys"]
+    assert not any(k in out["oneshot"]["keys"] for k in (113, 114, 115, 116, 23, 24, 105, 125)), out["oneshot"]["keys"]
 
 
 def test_matrix_rate_probe_is_plausible():

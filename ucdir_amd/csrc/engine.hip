@@ -21,6 +21,7 @@
 #include "akgm_pre.hip.h"
 #include "akgm_ws.hip.h"
 #include "akgm_ws32.hip.h"
+#include "akgm_ws64.hip.h"
 #include "conv_ws.hip.h"
 #include "conv_sk.hip.h"
 #include "conv_ws128.hip.h"
@@ -113,6 +114,7 @@ struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
     bf16_t* Apre = nullptr;        // cg 8 / 16: LDS image for akgm_pre.hip.h
     bf16_t* Aws32 = nullptr;       // cg 8 / 16 / 32: A fragments of akgm_ws32_kernel<cg>
+    bf16_t* Aws64 = nullptr;       // cg 64 (C = 512): A fragments of akgm_ws64_kernel, one half group per workgroup
     int C = 0, cg = 0, Kpad = 0;
 };
 
@@ -154,6 +156,7 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
     if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
     if (P.cg == 32 || P.cg == 16 || P.cg == 8) W.Aws32 = pool.upload(pack_akgm_ws32(wsp, gamma, C));
+    if (P.cg == 64 && C == 512) W.Aws64 = pool.upload(pack_akgm_ws64(wsp, gamma, C));
     return W;
 }
 
@@ -208,6 +211,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel<8>, AkWs::LDS); set_lds_attr(akgm_ws_kernel<16>, AkWs::LDS);
     set_lds_attr(akgm_ws32_kernel<32>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<16>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<8>, AkWs32::LDS);
+    set_lds_attr(akgm_ws64_kernel, AkWs64::LDS);
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
@@ -799,8 +803,26 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && (w.cg == 32 || (wsb_all && (w.cg == 16 || w.cg == 8))) && w.C == 8 * w.cg && th32 > 0 && y.W % 8 == 0 &&
                       (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * nb32 >= 4LL * num_cus());
     if (ws32) { p.A = w.Aws32; p.th = th32; p.tw = 8; p.tiles_x = y.W / 8; p.tiles_y = y.H / th32; }
+    // 64 channels per group (C = 512: the 36^2 / 18^2 levels): one HALF group per workgroup, linear tiles of 64 | 128 positions of the
+    // zero-bordered plane (akgm_ws64.hip.h); 16 roles x (CUs / 16) tile ranges.  From two tiles per range on (B = 1 keeps the one-shot
+    // kernel and its unit split); UCDIR_NO_WS64 falls back to akgm_halo_stage_kernel
+    static const bool use_ws64 = !getenv("UCDIR_NO_WS64");
+    int npt64 = 0, tps64 = 0, grid64 = 0;
+    if (use_ws && use_ws64 && w.Aws64 != nullptr && w.cg == 64 && w.C == 512 && y.H >= 2 && (y.H + 2) * (y.W + 2) < 32768) {
+        grid64 = num_cus() / 16 * 16; if (grid64 < 16) grid64 = 16;
+        const int span = (y.H - 1) * (y.W + 2) + y.W, nslots = grid64 / 16;
+        for (int cand : {4, 2}) {
+            if (32 * cand + 2 * (y.W + 2) + 2 > AkWs64::HPOS) continue;
+            const int tps = (span + 32 * cand - 1) / (32 * cand);
+            if (g_persist_grid > 0 || (long long)y.B * tps >= (cand == 4 ? 4LL : 2LL) * nslots) { npt64 = cand; tps64 = tps; break; }
+        }
+    }
+    const bool ws64 = npt64 > 0;
+    if (ws64) { p.A = w.Aws64; p.th = npt64; p.tw = 0; p.tiles_x = tps64; p.tiles_y = 1; }
     auto launch = [&]() {
-        if (ws32) {
+        if (ws64) {
+            hipLaunchKernelGGL(akgm_ws64_kernel, dim3(grid64), dim3(HC_THREADS), AkWs64::LDS, st, p);
+        } else if (ws32) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y;
             int ncu = num_cus() / nb32 * nb32; if (ncu < nb32) ncu = nb32;
             const int grid = nb32 * ntiles < ncu ? nb32 * ntiles : ncu;      // one workgroup per 32-feature block per tile range
@@ -838,7 +860,7 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
 #endif
     if (g_prof.on) {
-        ProfEntry e; e.key = ws32 ? 115 : (ws ? 113 : (ws16 ? 114 : (pre ? 112 : 111))); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
+        ProfEntry e; e.key = ws64 ? 116 : ws32 ? 115 : (ws ? 113 : (ws16 ? 114 : (pre ? 112 : 111))); e.flops = 2.0 * 9 * w.C * (double)w.C * y.H * y.W * y.B;
         e.bytes = (3.0 * w.C * 2 + 32) * (double)y.H * y.W * y.B + 9.0 * w.C * w.C * 2;
         e.dH = y.H; e.dW = y.W; e.dCin = w.C; e.dCout = w.C;
         e.e0 = g_prof.get(); e.e1 = g_prof.get();

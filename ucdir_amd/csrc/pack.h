@@ -299,6 +299,28 @@ static inline std::vector<bf16_t> pack_akgm_ws32(const float* wsp, const float* 
     return img;
 }
 
+// A fragments of akgm_ws64_kernel (akgm_ws64.hip.h; 64 channels per group, C = 512): [half group hg 16][wave 8][k step j 36][lane half hk][32 rows][8]
+// bf16.  Row rho of wave w: feature 32 hg + 4 w + 2 ((rho >> 2) & 1) + (rho >> 4), kernel set 4 ((rho >> 3) & 1) + (rho & 3) - a lane's 16
+// accumulators are then 2 features x 8 sets (as pack_akgm_ws32); k step j: tap j / 4, channels 16 (j & 3) + 8 hk + e of the group.
+// Values are W * gamma rounded exactly as in pack_akgm (same fold tables).
+static inline std::vector<bf16_t> pack_akgm_ws64(const float* wsp, const float* gamma, int C) {
+    const int cg = C / 8, nk = 36, nh = C / 32;
+    std::vector<bf16_t> img((size_t)nh * 8 * nk * 2 * 32 * 8, 0);
+    for (int hg = 0; hg < nh; ++hg)
+        for (int w = 0; w < 8; ++w)
+            for (int rho = 0; rho < 32; ++rho) {
+                const int c4 = 2 * ((rho >> 2) & 1) + (rho >> 4), sm = 4 * ((rho >> 3) & 1) + (rho & 3);
+                const int c = 32 * hg + 4 * w + c4, o = 8 * c + sm, g = c / cg;
+                for (int j = 0; j < nk; ++j)
+                    for (int hk = 0; hk < 2; ++hk)
+                        for (int e = 0; e < 8; ++e) {
+                            const int tap = j >> 2, ci = 16 * (j & 3) + 8 * hk + e;
+                            img[(((((size_t)hg * 8 + w) * nk + j) * 2 + hk) * 32 + rho) * 8 + e] = f2bf(wsp[((size_t)o * cg + ci) * 9 + tap] * gamma[g * cg + ci]);
+                        }
+            }
+    return img;
+}
+
 // A fragments of stem_mfma_kernel (misc.hip.h): [C0/64 blocks][tm 2][k16 step j 5][lane 64][8] bf16; lane = (k half
 // hh = lane >> 5, row = lane & 31): tap 2j + hh, channel slot e (e >= cin zero).  The tenth tap slot (j = 4, hh = 1)
 // carries the BIAS as bf16 hi + lo parts in slots 0 and 1 (the kernel feeds it the constant (1, 1, 0, ...)), so the
