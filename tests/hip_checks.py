@@ -209,24 +209,32 @@ def build_net(cfg: UNetConfig, seed=0):
     return net, O.to_torch_sd(np_sd)
 
 
-def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=None):
+def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=None, emu=False):
+    """HIP forward vs the fp32 oracle (``eps``, and per layer with ``taps``).  ``emu``: also against the oracle's bf16-emulation
+    mode (oracle.dy3h_naive_forward_emu: rounding where the kernels round), final output ``eps_emu`` and per layer ``<name>@emu``:
+    what is left between HIP and the emulation is summation order, not the rounding plan, so that bound is several times tighter."""
     net, sd = net_sd if net_sd is not None else build_net(cfg)
     cond, guide, x_t = synth_inputs(B, H, W, seed=seed)
     cond, guide, x_t = map(torch.from_numpy, (cond, guide, x_t))
     lvl = torch.tensor(levels, dtype=torch.float32).view(B, 1)
     x6 = torch.cat([cond, x_t], 1)
     otaps = {} if taps else None
+    etaps = {} if (taps and emu) else None
+    ph, pw = O.pad32(H), O.pad32(W)
     if taps:
-        ph, pw = O.pad32(H), O.pad32(W)
         ref_full = O.dy3h_naive_forward(sd, F.pad(x6, (0, pw, 0, ph), mode="reflect"), lvl,
                                         F.pad(guide, (0, pw, 0, ph), mode="reflect"), taps=otaps)
         ref = ref_full[..., :-ph, :-pw]
     else:
         ref = O.dy3h_forward(sd, x6, lvl, guide)
+    ref_emu = O.dy3h_forward(sd, x6, lvl, guide, emulate_bf16=True, taps=etaps) if emu else None
     with torch.no_grad():
         eps = net.denoise_fn(x6.to(DEV), lvl.to(DEV), guide.to(DEV))
     torch.cuda.synchronize()
     out = {"eps": metrics(eps, ref)}
+    if emu:
+        out["eps_emu"] = metrics(eps, ref_emu)
+        out["emu_vs_oracle"] = metrics(ref_emu, ref)
     if taps:
         from ucdir_amd.spec import unet_layers
         for Ld in unet_layers(cfg):
@@ -234,10 +242,14 @@ def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=N
             got = net.denoise_fn.debug_read(Ld.name, "out")
             torch.cuda.synchronize()
             out[Ld.name] = metrics(got, otaps[key])
+            if emu:
+                out[Ld.name + "@emu"] = metrics(got, etaps[key])
             if Ld.kind == "block":
                 got = net.denoise_fn.debug_read(Ld.name, "h1")
                 torch.cuda.synchronize()
                 out[Ld.name + ":h1"] = metrics(got, otaps[key + ".res_block.h1"])
+                if emu:
+                    out[Ld.name + ":h1@emu"] = metrics(got, etaps[key + ".res_block.h1"])
     return out, eps.cpu(), ref
 
 

@@ -111,8 +111,10 @@ def test_conv_persistent(args):
     (2, 50, 70, 64, 0, 128, 0, True, True, False, 0),       # two strips of 35 columns (4-wave kind), ragged in every direction
     (1, 40, 100, 64, 0, 256, 2, False, False, False, 0),    # Upsample on strips
     (16, 36, 36, 512, 0, 512, 0, True, True, False, 0),     # the 36^2 level of the bench configuration
+    (4, 20, 24, 128, 0, 256, 0, True, True, False, 8),      # kind 1: 9 units of 4 chunks on 8 workgroups: a remainder of ONE unit has fewer chunks than workgroups
+                                                            # (round-4 advice: workgroups without a range must not contribute stale partial slots)
 ], ids=["fold_ragged", "cat_samples", "streamk_3wg", "res_streamk_7wg", "up_256", "up_streamk", "cat_chunks", "level4_b16",
-        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide", "strips_ragged", "strips_up", "level3_b16"])
+        "rows128", "rows128_res_streamk", "rows128_up", "rows128_wide", "strips_ragged", "strips_up", "level3_b16", "short_remainder"])
 @pytest.mark.parametrize("kind", [1, 2], ids=["persistent8", "oneshot4"])
 def test_conv_stream_k(args, kind):
     """conv_sk_kernel (persistent stream-K 3x3 conv / Upsample parity classes on 256-row x 256-position linear tiles) + its finish

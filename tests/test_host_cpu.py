@@ -253,6 +253,41 @@ def test_seeded_noise_is_identical_across_instances():
     assert torch.equal(a._noise(like, 0), draws[0][0])
 
 
+def test_sampler_releases_the_weight_check_hold_when_its_setup_raises():
+    """Round-4 advice: _begin() sets the denoiser's hold flag; every sampler enters its try / finally at once, so a failure in
+    the setup behind it (noise source, buffer allocation) still runs _end(): the hold is released and the patch cache cleared."""
+    from ucdir_amd.diffusion import GaussianDiffusion
+
+    class Den(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.hold, self.cleared, self.patch_threshold = False, 0, 1 << 30
+        def hold_weight_check(self, on): self.hold = bool(on)
+        def clear_patch_cache(self): self.cleared += 1
+
+    gd = GaussianDiffusion(Den(), 128)
+    gd.set_new_noise_schedule(dict(schedule="linear", n_timestep=8, linear_start=1e-6, linear_end=0.4), torch.device("cpu"))
+
+    def boom(*a, **k):
+        raise RuntimeError("noise source failed")
+    gd._start_noise = boom
+    x = torch.zeros(1, 3, 8, 8)
+    for call in (lambda: gd.p_sample_loop(x), lambda: gd.ddim_sample(x), lambda: gd.dpm_solver_sample(x)):
+        n = gd.denoise_fn.cleared
+        with pytest.raises(RuntimeError, match="noise source failed"):
+            call()
+        assert gd.denoise_fn.hold is False and gd.denoise_fn.cleared == n + 1
+
+
+def test_patch_window_list_is_validated_before_upload():
+    from ucdir_amd import patch as P
+    wins = P.patch_windows(1680, 2384, 1024, 64)
+    P._check_windows(wins, 1680, 2384, 1024)                               # the scheduler's own list passes
+    for bad in [(0, 1024, 1400, 2424), (-8, 1016, 0, 1024), (0, 1000, 0, 1024), (700, 1724, 0, 1024)]:
+        with pytest.raises(ValueError, match="patch window"):
+            P._check_windows([bad], 1680, 2384, 1024)
+
+
 def test_config_overrides_gopro_and_jpeg(tmp_path):
     import yaml
     base = yaml.safe_load(open(os.path.join(ROOT, "config", "sid.yaml")))

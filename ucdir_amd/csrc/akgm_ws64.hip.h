@@ -20,23 +20,39 @@
 #pragma once
 #include "akgm_ws32.hip.h"
 
-struct AkWs64 {
+template <int NW> struct AkWs64 {
     static constexpr int HPOS = 272;                              // halo positions per buffer: NPX + 2 (W + 2) + 2 <= 272
     static constexpr int HALO = HPOS * 128;                       // 34,816 = 17 x 2048: the swizzle survives the buffer switch
+    static constexpr int HBYTES(int hpos) { return ((hpos + 15) / 16) * 2048; }
     static constexpr int PSTEP = 32 * 128;                        // one pixel tile = 32 positions further
-    static constexpr int STAGE = 128 * 64;                        // [128 positions][64 B] residual in / result out
+    static constexpr int SEGB = 8 * NW;                           // bytes of a position this workgroup produces (4 NW features)
+    static constexpr int CPS = SEGB / 16;                         // 16-byte chunks per segment
+    static constexpr int STAGE = 128 * SEGB;                      // [128 positions][SEGB] residual in / result out
     static constexpr int ATT = 128 * 32;                          // [128 positions][8] fp32
-    static constexpr int OFF_STAGE = 2 * HALO;
-    static constexpr int OFF_ATT = OFF_STAGE + 2 * STAGE;
-    static constexpr int OFF_TCS = OFF_ATT + 2 * ATT;             // [9][256] fp32
-    static constexpr int LDS = OFF_TCS + 9 * 1024;                // 103,424
+    static constexpr int TCS = 9 * 32 * NW * 4;                   // [9][32 NW] fp32
     static constexpr int NK = 36;                                 // k steps: tap j / 4, channels 16 (j & 3) .. + 15
+    // dynamic LDS for a halo of hpos positions: 2 halo buffers | 2 staging slots | 2 guide buffers | fold table
+    static constexpr int lds(int hpos) { return 2 * HBYTES(hpos) + 2 * STAGE + 2 * ATT + TCS; }
 };
 
-// p.th = pixel tiles per tile (2 | 4), p.tiles_x = tiles per sample, p.tiles_y unused (1)
-__global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p) {
-    constexpr int NK = AkWs64::NK;
+// one LDS-DMA piece (1 KB: 64 lanes x 16 B) from a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset to a wave-uniform
+// LDS address: no 64-bit VALU address arithmetic per piece, and hipcc does not count it (cdna guide 5.7): the kernel waits for its DMAs at the
+// tile top by hand, and no compiler-made LDS access is held back by a vmcnt(0) for a DMA the compiler knows nothing about
+__device__ __forceinline__ void w64_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// NPT = pixel tiles per tile (2 | 4: 64 | 128 positions); NW = waves per workgroup (8: half a group per workgroup, one workgroup per CU;
+// 4: a QUARTER group - 16 features x 8 sets = 128 rows - per workgroup, 80 KB of LDS: TWO independent workgroups per CU, so the two waves
+// of a SIMD belong to different workgroups and no barrier aligns them).  p.tiles_x = tiles per sample, p.tiles_y unused (1), p.tw = halo bytes
+template <int NPT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
+    using L = AkWs64<NW>;
+    constexpr int NK = L::NK;
     constexpr int CPX = 512;                                       // channels per position
+    constexpr int NPX = 32 * NPT;
+    constexpr int FEAT = 4 * NW;                                   // output features of the workgroup
+    constexpr int PP = 1024 / L::SEGB;                             // positions per residual / output piece of 1 KB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,81 +62,93 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int nslots = (int)gridDim.x >> 4;                        // tile ranges per role (the grid is a multiple of 16)
-    const int hg = lid / nslots, slot = lid - hg * nslots;         // half group 0 .. 15, range
-    const int NPT = p.th, NPX = 32 * NPT;
+#ifndef W64_DBGWAVE
+#define W64_DBGWAVE (NW - 3)
+#endif
+#ifdef UCDIR_TIMING
+    const bool dbg_on = p.dbg && (lid == (int)gridDim.x / 2 + 3) && (lane == 0) && (wave == W64_DBGWAVE);
+    int dbg_n = 0;
+#define W64_STAMP() do { if (dbg_on && dbg_n < 250) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W64_STAMP() do {} while (0)
+#endif
+    W64_STAMP();
+    constexpr int NROLE = 512 / FEAT;                              // 16 half groups | 32 quarter groups
+    const int nslots = (int)gridDim.x / NROLE;                     // tile ranges per role (the grid is a multiple of NROLE)
+    const int role = lid / nslots, slot = lid - role * nslots;     // roles of one group sit on one XCD (XCD-contiguous lid): its halo lines stay in that L2
     const int Wp = p.Wp, Ptot = (p.H + 2) * Wp, Plast = p.H * Wp + p.W;     // positions of a sample; last valid position
     const float inv_wp = 1.0f / (float)Wp;
     const int tps = p.tiles_x, T = p.nbatch * tps;
     const int t_beg = (int)((long long)slot * T / nslots), t_end = (int)((long long)(slot + 1) * T / nslots);
     if (t_beg >= t_end) return;
-    const int chan0 = 32 * hg;                                     // this workgroup's first output channel (64 bytes of a position)
+    const int chan0 = FEAT * role;                                 // this workgroup's first output channel
+    const int gch0 = 64 * (chan0 >> 6);                            // its group's first input channel
+    const int HB = p.tw;                                           // bytes per halo buffer (a multiple of 2048)
+    const unsigned OFF_STAGE = 2 * HB, OFF_ATT = OFF_STAGE + 2 * L::STAGE, OFF_TCS = OFF_ATT + 2 * L::ATT;
 
     // ---- this wave's weights, resident ------------------------------------------------------------------------------------
     bf16x8_t af[NK];
     {
-        const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + ((long long)(hg * 8 + wave) * NK) * 1024 + lane * 16;
+        const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A) + ((long long)(role * NW + wave) * NK) * 1024 + lane * 16;
 #pragma unroll
         for (int j = 0; j < NK; ++j) af[j] = *reinterpret_cast<const bf16x8_t*>(Ab + j * 1024);
     }
 #pragma unroll
     for (int j = 0; j < NK; ++j) asm volatile("" : "+v"(af[j]));
+    W64_STAMP();                                                   // weights resident
 
     // ---- tile-invariant lane constants ---------------------------------------------------------------------------------
-    // halo piece k (8 positions x 128 B): wave w stages pieces w, w + 8, ...; lane -> (position 8 k + lane / 8, physical chunk lane & 7)
+    // halo piece k (8 positions x 128 B): wave w stages pieces w, w + NW, ...; lane -> (halo position 8 k + lane / 8, physical chunk lane & 7);
+    // the logical chunk is physical ^ (position >> 1) & 7 = physical ^ (4 (k & 1) + lane / 16)
     const int npiece = (NPX + 2 * Wp + 2 + 7) >> 3;
-    int hsw[5];                                                    // channel offset of the lane's logical chunk (elements), per piece
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int hp = 8 * (i * 8 + wave) + (lane >> 3);
-        hsw[i] = 64 * (hg >> 1) + (((lane & 7) ^ ((hp >> 1) & 7)) << 3);
-    }
+    constexpr int NHOP = (L::HPOS / 8 + NW - 1) / NW;              // halo DMA operations per wave at most (5 | 9)
     // B fragment of tap t, channel quarter 0, pixel tile 0, buffer 0: LDS byte address (quarter cq: ^ (cq << 5); pixel tile q: + q PSTEP)
     unsigned bt[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int hp = l31 + (t / 3) * Wp + t % 3;
-        bt[t] = hp * 128 + ((hh ^ ((hp >> 1) & 7)) << 4) + AkWs64::HALO;          // (flipped to buffer 0 at the top of the first tile)
+        bt[t] = hp * 128 + ((hh ^ ((hp >> 1) & 7)) << 4) + HB;                     // (flipped to buffer 0 at the top of the first tile)
     }
-    const unsigned tc_lane = AkWs64::OFF_TCS + 4 * 8 * (4 * wave + 2 * hh);              // + 1024 cls: this lane's 16 table entries (2 features x 8 sets)
-    const unsigned att_lane = AkWs64::OFF_ATT + l31 * 32;                                // + 1024 q: this lane's position of pixel tile q
-    // this lane's 4 bytes (features 4 w + 2 hh, + 1) of position 32 q + l31 in the staging slot: chunk w / 2 ^ (pos >> 2) & 3, + 8 (w & 1) + 4 hh
-    const unsigned st_lane = AkWs64::OFF_STAGE + l31 * 64 + (((wave >> 1) ^ ((l31 >> 2) & 3)) << 4) + 8 * (wave & 1) + 4 * hh;   // + 2048 q
-    // residual piece `wave` (16 positions x 64 B): lane -> (position 16 w + lane / 4, physical chunk lane & 3)
-    const int rpos = 16 * wave + (lane >> 2);
-    const int rsw = chan0 + (((lane & 3) ^ ((rpos >> 2) & 3)) << 3);
-    // guide piece `wave` (32 positions x 32 B): lane -> (position 32 w + lane / 2, half lane & 1)
-    const int gpos = 32 * wave + (lane >> 1);
-    // line mover: thread -> (position tid / 4, physical chunk tid & 3) = its wave's residual piece
-    const int mpos = tid >> 2;
-    const int msw = chan0 + (((tid & 3) ^ ((mpos >> 2) & 3)) << 3);
+    const unsigned tc_lane = OFF_TCS + 4 * 8 * (4 * wave + 2 * hh);                      // + 128 NW cls: this lane's 16 table entries (2 features x 8 sets)
+    const unsigned att_lane = OFF_ATT + l31 * 32;                                        // + 1024 q: this lane's position of pixel tile q
+    // this lane's 4 bytes (features 4 w + 2 hh, + 1) of position 32 q + l31 in the staging slot: chunk w / 2 ^ (pos >> 2) & (CPS - 1), + 8 (w & 1) + 4 hh
+    const unsigned st_lane = OFF_STAGE + l31 * L::SEGB + (((wave >> 1) ^ ((l31 >> 2) & (L::CPS - 1))) << 4) + 8 * (wave & 1) + 4 * hh;   // + 32 SEGB q
 
     int b = t_beg / tps, ti = t_beg - b * tps;                      // tile t = (sample b, tile ti of the sample)
-    auto issue_tile = [&](int nb, int nti, int buf) {
-        const int P0 = Wp + 1 + nti * NPX;                          // first output position; the halo starts Wp + 1 positions earlier
-        const bf16_t* hb = p.h + (long long)nb * p.h_bstride;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k = i * 8 + wave;
+    // DMA operation `op` of tile (nb, nti) into buffer buf: 0 .. NHOP - 1 = this wave's halo pieces NW op + w, NHOP = its guide piece (32
+    // positions x 32 B, waves < NPT), NHOP + 1 = its residual piece (PP positions x SEGB, pieces < NPX / PP)
+    auto dma_op = [&](auto opc, int nb, int nti, int buf) {
+        constexpr int op = decltype(opc)::value;
+        // the per-lane offsets are formed HERE (three or four VALU per piece), from a lane id that is opaque at this point: hoisted to
+        // the tile top they were seven more registers live across the K loops (spills)
+        unsigned ln = lane;
+        asm volatile("" : "+v"(ln));
+        if constexpr (op < NHOP) {
+            const int k = op * NW + wave;
             if (k < npiece) {
-                int sp = nti * NPX + 8 * k + (lane >> 3);
+                int sp = nti * NPX + 8 * k + (int)(ln >> 3);
                 sp = sp < Ptot ? sp : Ptot - 1;                     // (the last tile's halo may run past the sample: clamped, feeds dropped positions only)
-                stage16(hb + (long long)sp * CPX + hsw[i], smem + buf * AkWs64::HALO + k * 1024, lane);
+                const unsigned off = (unsigned)sp * (CPX * 2) + (unsigned)(gch0 + (((ln & 7) ^ (4 * (k & 1) + (ln >> 4))) << 3)) * 2;
+                w64_dma16(p.h + (long long)nb * p.h_bstride, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * HB + k * 1024));
+            }
+        } else if constexpr (op == NHOP) {
+            if (wave < NPT) {
+                int P = Wp + 1 + nti * NPX + 32 * wave + (int)(ln >> 1); P = P < Ptot ? P : Ptot - 1;
+                int y = fdiv_small(P, inv_wp), x = P - y * Wp;
+                y = y < 1 ? 1 : (y > p.H ? p.H : y); x = x < 1 ? 1 : (x > p.W ? p.W : x);
+                w64_dma16(p.G + (long long)nb * p.g_bstride, (unsigned)((((y - 1) * p.W + (x - 1)) * 8 + (int)(ln & 1) * 4) * 4),
+                          (unsigned)__builtin_amdgcn_readfirstlane(OFF_ATT + buf * L::ATT + wave * 1024));
+            }
+        } else {
+            if (wave < NPX / PP) {
+                const unsigned pos = PP * wave + ln / L::CPS;
+                int P = Wp + 1 + nti * NPX + (int)pos; P = P < Ptot ? P : Ptot - 1;
+                const unsigned off = (unsigned)P * (CPX * 2) + (unsigned)(chan0 + (((ln & (L::CPS - 1)) ^ ((pos >> 2) & (L::CPS - 1))) << 3)) * 2;
+                w64_dma16(p.res + (long long)nb * p.res_bstride, off, (unsigned)__builtin_amdgcn_readfirstlane(OFF_STAGE + buf * L::STAGE + wave * 1024));
             }
         }
-        if (wave < NPT) {
-            int P = P0 + gpos; P = P < Ptot ? P : Ptot - 1;
-            int y = fdiv_small(P, inv_wp), x = P - y * Wp;
-            y = y < 1 ? 1 : (y > p.H ? p.H : y); x = x < 1 ? 1 : (x > p.W ? p.W : x);
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.G + (long long)nb * p.g_bstride + ((y - 1) * p.W + (x - 1)) * 8 + (lane & 1) * 4),
-                                             (LDS_AS void*)(smem + AkWs64::OFF_ATT + buf * AkWs64::ATT + wave * 1024), 16, 0, 0);
-        }
-        if (wave < 2 * NPT) {
-            int P = P0 + rpos; P = P < Ptot ? P : Ptot - 1;
-            stage16(p.res + (long long)nb * p.res_bstride + (long long)P * CPX + rsw, smem + AkWs64::OFF_STAGE + buf * AkWs64::STAGE + wave * 1024, lane);
-        }
     };
-    issue_tile(b, ti, 0);
+    static_for<0, NHOP + 2>([&](auto opc) { dma_op(opc, b, ti, 0); });
 
     int b_cur = -1;
     float rstd = 1.f, aw[8];
@@ -133,12 +161,19 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
 #pragma unroll 1
     for (int t = t_beg; t <= t_end; ++t) {
         const int buf = (t - t_beg) & 1;
-        // every LDS-DMA of this tile (issued one tile ago) has landed; every wave is done with the previous tile (its results are
-        // in the other staging slot, its halo buffer is free)
+        // every LDS-DMA of this tile (issued during the previous tile) has landed; every wave is done with the previous tile (its
+        // results are in the other staging slot, its halo buffer is free)
+        W64_STAMP();                                                // tile top
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (have_prev) {                                            // the previous tile's finished 64-byte segments out
-            if (prev_out >= 0) {
-                const u32x4_t ln = *reinterpret_cast<const u32x4_t*>(smem + AkWs64::OFF_STAGE + (buf ^ 1) * AkWs64::STAGE + tid * 16);
+        W64_STAMP();                                                // behind the barrier
+        if (have_prev) {                                            // the previous tile's finished segments out
+#ifndef W64_ABL_NOSTORE
+            if (prev_out >= 0)
+#else
+            if (prev_out == -12345)
+#endif
+            {
+                const u32x4_t ln = *reinterpret_cast<const u32x4_t*>(smem + OFF_STAGE + (buf ^ 1) * L::STAGE + tid * 16);
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(p.out) + prev_out) = ln;
             }
         }
@@ -150,12 +185,17 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
             }
             S1 = 0; S2 = 0;
             b_cur = b;
+            // fold table slice [9][32 NW] of this sample: piece pc = classes (NW == 8: pc, 64 lanes x 16 B; NW == 4: 2 pc and 2 pc + 1, 32 lanes each)
+            constexpr int NTP = (NW == 8) ? 9 : 5;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int pc = i * 8 + wave;
-                if (pc < 9)
-                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + pc) * (8 * CPX) + 256 * hg + lane * 4),
-                                                     (LDS_AS void*)(smem + AkWs64::OFF_TCS + pc * 1024), 16, 0, 0);
+            for (int i = 0; i < (NTP + NW - 1) / NW; ++i) {
+                const int pc = i * NW + wave;
+                if (pc < NTP) {
+                    const int cl = (NW == 8) ? pc : 2 * pc + (lane >> 5), e4 = (NW == 8) ? lane : (lane & 31);
+                    if (cl < 9)
+                        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + cl) * (8 * CPX) + 8 * chan0 + e4 * 4),
+                                                         (LDS_AS void*)(smem + OFF_TCS + pc * 1024), 16, 0, 0);
+                }
             }
             rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
 #pragma unroll
@@ -166,18 +206,21 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
         const bool last = t + 1 == t_end;
         int nb = b, nti = ti + 1;
         if (nti == tps) { nti = 0; ++nb; }
-        // (the staging slot buf ^ 1 was just read by the stores above: the DMA of the next tile's residual goes behind them in
-        // program order; LDS reads of a wave complete before its later LDS-DMA writes are issued: the data is in registers)
+        // (the staging slot buf ^ 1 was just read by the store above: the DMA of the next tile's residual goes behind it in program
+        // order, the data is in registers by then)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!last) issue_tile(nb, nti, buf ^ 1);
+        W64_STAMP();                                                // stores issued
+#ifndef W64_ABL_NODMA
+        if (!last) static_for<0, NHOP + 2>([&](auto opc) { dma_op(opc, nb, nti, buf ^ 1); });
+#endif
 
         const int P0 = Wp + 1 + ti * NPX;
-        const unsigned ab0 = buf * AkWs64::ATT, sb0 = buf * AkWs64::STAGE;
+        const unsigned ab0 = buf * L::ATT, sb0 = buf * L::STAGE;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) bt[k] = buf ? bt[k] + AkWs64::HALO : bt[k] - AkWs64::HALO;       // in place: 9 registers, not 18
+        for (int k = 0; k < 9; ++k) bt[k] = buf ? bt[k] + HB : bt[k] - HB;       // in place: 9 registers, not 18
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll 1
-        for (int qp = 0; qp < NPT; qp += 2) {                       // two pixel tiles at a time (NPT is even)
+        for (int qp = 0; qp < NPT; qp += 2) {                       // two pixel tiles at a time
             f32x16_t acc[2];
             bool valid[2];
 #pragma unroll
@@ -187,23 +230,29 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
                 valid[tq] = x >= 1 && x <= p.W && P <= Plast;
                 const int cy = (y <= 1) ? 0 : ((y >= p.H) ? 2 : 1);
                 const int cx = (x <= 1) ? 0 : ((x >= p.W) ? 2 : 1);
-                const unsigned tca = tc_lane + (cy * 3 + cx) * 1024;
+                const unsigned tca = tc_lane + (cy * 3 + cx) * (128 * NW);
+#ifdef W64_ABL_NOINIT
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[tq][e] = (float)tca;
+#else
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 16 * g4);
                     acc[tq][4 * g4 + 0] = c4[0]; acc[tq][4 * g4 + 1] = c4[1]; acc[tq][4 * g4 + 2] = c4[2]; acc[tq][4 * g4 + 3] = c4[3];
                 }
+#endif
             }
             // K loop software-pipelined by hand (inline-asm fragment reads, counted lgkmcnt; see akgm_ws.hip.h): the fragments of
             // steps j + 1 and j + 2 are in flight under the two MFMAs of step j (64 matrix-core cycles < one LDS round trip)
             bf16x8_t bfr[3][2];
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fold constants; nothing of the compiler's own is queued behind this
+            W64_STAMP();                                            // accumulators initialised
             auto frag = [&](auto jc, bf16x8_t (&dst)[2]) {
                 constexpr int j = decltype(jc)::value;
                 const unsigned a0 = bt[j >> 2] ^ ((j & 3) << 5);
                 lds_read16_asm<0>(dst[0], a0);
-                lds_read16_asm<AkWs64::PSTEP>(dst[1], a0);
+                lds_read16_asm<L::PSTEP>(dst[1], a0);
             };
             frag(std::integral_constant<int, 0>{}, bfr[0]);
             frag(std::integral_constant<int, 1>{}, bfr[1]);
@@ -217,7 +266,11 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
                 for (int tq = 0; tq < 2; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bfr[j % 3][tq], acc[tq], 0, 0, 0);
             });
             __builtin_amdgcn_s_setprio(0);
+            W64_STAMP();                                            // K loop done
             // ---- modulation sum, swish, residual, statistics; the lane's two features go back into the staging slot -------------
+#ifdef W64_ABL_NOEPI
+            s1 += acc[0][0] + acc[1][5];
+#else
 #pragma unroll
             for (int tq = 0; tq < 2; ++tq) {
                 const unsigned aq = att_lane + ab0 + (qp + tq) * 1024;
@@ -231,7 +284,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
                     for (int s = 0; s < 8; ++s) sa += att[s] * acc[tq][8 * k + s];
                     o2[k] = rstd * sa;
                 }
-                const unsigned sa = st_lane + sb0 + (qp + tq) * 2048;
+                const unsigned sa = st_lane + sb0 + (qp + tq) * (32 * L::SEGB);
                 const unsigned rv = *reinterpret_cast<const unsigned*>(smem + sa);
                 float v0 = silu_fast(o2[0]) + __builtin_bit_cast(float, rv << 16);
                 float v1 = silu_fast(o2[1]) + __builtin_bit_cast(float, rv & 0xffff0000u);
@@ -239,21 +292,25 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws64_kernel(const AkgmHP p
                 v0 = valid[tq] ? v0 : 0.f; v1 = valid[tq] ? v1 : 0.f;        // border columns / positions past the sample: dropped
                 s1 += v0 + v1; s2 += v0 * v0 + v1 * v1;
             }
+#endif
 #pragma unroll
-            for (int k = 0; k < 9; ++k) bt[k] += 2 * AkWs64::PSTEP;
+            for (int k = 0; k < 9; ++k) bt[k] += 2 * L::PSTEP;
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) bt[k] -= NPT * AkWs64::PSTEP;
+        for (int k = 0; k < 9; ++k) bt[k] -= NPT * L::PSTEP;
         S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
         have_prev = true;
         {
-            const int P = P0 + mpos;
+            const int mpos = tid / L::CPS, P = P0 + mpos;
             const int y = fdiv_small(P < Ptot ? P : Ptot - 1, inv_wp), x = P - y * Wp;
             const bool ok = mpos < NPX && x >= 1 && x <= p.W && P <= Plast;
-            prev_out = ok ? ((long long)b * p.out_bstride + (long long)P * CPX + msw) * 2 : -1;
+            prev_out = ok ? ((long long)b * p.out_bstride + (long long)P * CPX + chan0 + (((tid & (L::CPS - 1)) ^ ((mpos >> 2) & (L::CPS - 1))) << 3)) * 2 : -1;
         }
         b = nb; ti = nti;
     }
+#ifdef UCDIR_TIMING
+    if (dbg_on) p.dbg[255] = dbg_n;
+#endif
     if (p.stats_out) {
         const stat_t a = wave_sum_ll(S1), q2 = wave_sum_ll(S2);
         if (lane == 0) stat_add_fx(p.stats_out, b_cur, a, q2);

@@ -807,7 +807,8 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         return p.partial + ((long long)(2 * gg + (first ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4 + fo;
     };
     float4 v0[2][4], v1[2][4];
-    const bool two = g + 1 < G && sch.start(g + 1) < b;
+    // (workgroups with an empty chunk range - start(g) == start(g + 1) - wrote nothing in this launch: never a part)
+    const bool two = g + 1 < G && sch.start(g + 1) < b && sch.start(g + 2) > sch.start(g + 1);
     {
         const float* p0 = part_ptr(g);
         const float* p1 = part_ptr(two ? g + 1 : g);
@@ -836,6 +837,7 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
             }
     }
     for (g += two ? 2 : 1; g < G && sch.start(g) < b; ++g) {          // further parts, in part order
+        if (sch.start(g + 1) == sch.start(g)) continue;
         const float* pr = part_ptr(g);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {

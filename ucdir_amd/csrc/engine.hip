@@ -211,7 +211,8 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_pre_kernel<8>, AkPre<8>::LDS);
     set_lds_attr(akgm_ws_kernel<8>, AkWs::LDS); set_lds_attr(akgm_ws_kernel<16>, AkWs::LDS);
     set_lds_attr(akgm_ws32_kernel<32>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<16>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<8>, AkWs32::LDS);
-    set_lds_attr(akgm_ws64_kernel, AkWs64::LDS);
+    set_lds_attr(akgm_ws64_kernel<2, 4>, 160 * 1024); set_lds_attr(akgm_ws64_kernel<4, 4>, 160 * 1024);
+    set_lds_attr(akgm_ws64_kernel<2, 8>, 160 * 1024); set_lds_attr(akgm_ws64_kernel<4, 8>, 160 * 1024);
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
@@ -493,6 +494,13 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
             G = p.units * ksplit_env; p.ndp = 0; ksplit_on = true;
         } else if (mode < 0 && (p.units < num_cus() || p.nchunks < (upph ? 8 : 4))) return false;
     }
+    // A stream-K remainder with fewer chunks than workgroups would leave workgroups WITHOUT a chunk range: they write no partial slot, and the
+    // finish kernel must never take one of their (stale) slots for a part (round-4 advice).  One whole round of units joins the remainder
+    // instead, so that every workgroup owns at least one chunk; the finish kernel skips empty ranges as well
+    if (!ksplit_on) {
+        const long long rem = (long long)p.units - p.ndp;
+        if (rem > 0 && rem * p.nchunks < G && p.ndp >= G) p.ndp -= G;
+    }
     if (did_res) *did_res = false;
     if (NW == 4 && MW == 1 && !upph && res_out && wres && wres->Ask1x1 && wres->cout == w.cout && ((G == p.units && p.ndp == p.units) || ksplit_on)) {
         // the block's 1x1 res_conv as the grid's last workgroups (one per (row tile, pixel tile)): same input, its own weights and output
@@ -502,9 +510,9 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         if (did_res) *did_res = true;
     }
     const int Gmain = G - p.alt_units;                               // the workgroups of the unit schedule (the finish kernel's view)
-    p.partial = splitk_scratch();
     const size_t lds = L::lds_bytes(nhp);
     const int nsk = p.units - p.ndp;
+    p.partial = nsk > 0 ? splitk_scratch() : nullptr;                // (no cut unit, no partial tiles: the single-operator entry points do not allocate the scratch for nothing)
     auto go = [&]() {
         if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 4>), dim3(G), dim3(L::THREADS), lds, st, p);
         else hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 9>), dim3(G), dim3(L::THREADS), lds, st, p);
@@ -803,25 +811,40 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && (w.cg == 32 || (wsb_all && (w.cg == 16 || w.cg == 8))) && w.C == 8 * w.cg && th32 > 0 && y.W % 8 == 0 &&
                       (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * nb32 >= 4LL * num_cus());
     if (ws32) { p.A = w.Aws32; p.th = th32; p.tw = 8; p.tiles_x = y.W / 8; p.tiles_y = y.H / th32; }
-    // 64 channels per group (C = 512: the 36^2 / 18^2 levels): one HALF group per workgroup, linear tiles of 64 | 128 positions of the
-    // zero-bordered plane (akgm_ws64.hip.h); 16 roles x (CUs / 16) tile ranges.  From two tiles per range on (B = 1 keeps the one-shot
-    // kernel and its unit split); UCDIR_NO_WS64 falls back to akgm_halo_stage_kernel
+    // 64 channels per group (C = 512: the 36^2 / 18^2 levels), akgm_ws64.hip.h: a QUARTER group per workgroup of four waves, two
+    // independent workgroups per CU (UCDIR_WS64_NW=8: half a group per workgroup of eight waves, one per CU), linear tiles of 64 | 128
+    // positions of the zero-bordered plane; roles x (resident workgroups / roles) tile ranges.  From two tiles per range on (B = 1 keeps the
+    // one-shot kernel and its unit split); UCDIR_NO_WS64 falls back to akgm_halo_stage_kernel
     static const bool use_ws64 = !getenv("UCDIR_NO_WS64");
-    int npt64 = 0, tps64 = 0, grid64 = 0;
+    static const int ws64_nw = (getenv("UCDIR_WS64_NW") && atoi(getenv("UCDIR_WS64_NW")) == 8) ? 8 : 4;
+    int npt64 = 0, tps64 = 0, grid64 = 0, lds64 = 0;
     if (use_ws && use_ws64 && w.Aws64 != nullptr && w.cg == 64 && w.C == 512 && y.H >= 2 && (y.H + 2) * (y.W + 2) < 32768) {
-        grid64 = num_cus() / 16 * 16; if (grid64 < 16) grid64 = 16;
-        const int span = (y.H - 1) * (y.W + 2) + y.W, nslots = grid64 / 16;
+        const int nrole = 128 / ws64_nw, resident = (ws64_nw == 4 ? 2 : 1) * num_cus();
+        grid64 = resident / nrole * nrole; if (grid64 < nrole) grid64 = nrole;
+        const int span = (y.H - 1) * (y.W + 2) + y.W, nslots = grid64 / nrole;
         for (int cand : {4, 2}) {
-            if (32 * cand + 2 * (y.W + 2) + 2 > AkWs64::HPOS) continue;
+            const int hpos = 32 * cand + 2 * (y.W + 2) + 2;
+            if (hpos > AkWs64<4>::HPOS) continue;
             const int tps = (span + 32 * cand - 1) / (32 * cand);
-            if (g_persist_grid > 0 || (long long)y.B * tps >= (cand == 4 ? 4LL : 2LL) * nslots) { npt64 = cand; tps64 = tps; break; }
+            if (g_persist_grid > 0 || (long long)y.B * tps >= (cand == 4 ? 4LL : 2LL) * nslots) {
+                npt64 = cand; tps64 = tps;
+                lds64 = ws64_nw == 4 ? AkWs64<4>::lds(hpos) : AkWs64<8>::lds(hpos);
+                p.tw = AkWs64<4>::HBYTES(hpos);
+                break;
+            }
         }
     }
     const bool ws64 = npt64 > 0;
-    if (ws64) { p.A = w.Aws64; p.th = npt64; p.tw = 0; p.tiles_x = tps64; p.tiles_y = 1; }
+    if (ws64) { p.A = w.Aws64; p.th = npt64; p.tiles_x = tps64; p.tiles_y = 1; }
     auto launch = [&]() {
         if (ws64) {
-            hipLaunchKernelGGL(akgm_ws64_kernel, dim3(grid64), dim3(HC_THREADS), AkWs64::LDS, st, p);
+            if (ws64_nw == 4) {
+                if (npt64 == 4) hipLaunchKernelGGL((akgm_ws64_kernel<4, 4>), dim3(grid64), dim3(256), lds64, st, p);
+                else hipLaunchKernelGGL((akgm_ws64_kernel<2, 4>), dim3(grid64), dim3(256), lds64, st, p);
+            } else {
+                if (npt64 == 4) hipLaunchKernelGGL((akgm_ws64_kernel<4, 8>), dim3(grid64), dim3(512), lds64, st, p);
+                else hipLaunchKernelGGL((akgm_ws64_kernel<2, 8>), dim3(grid64), dim3(512), lds64, st, p);
+            }
         } else if (ws32) {
             const int ntiles = y.B * p.tiles_x * p.tiles_y;
             int ncu = num_cus() / nb32 * nb32; if (ncu < nb32) ncu = nb32;
@@ -1784,20 +1807,22 @@ int32_t ucdir_matrix_rate(int32_t iters, int32_t random, double* tflops, void* s
     API_BEGIN
     if (iters <= 0 || !tflops) throw std::runtime_error("ucdir_matrix_rate: iters > 0 and a result pointer are required");
     hipStream_t st = (hipStream_t)stream;
-    float* sink = nullptr;                                           // (per call, on the current device: a probe, not a hot path)
-    HIPC(hipMalloc((void**)&sink, 4));
-    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    // (per call, on the current device: a probe, not a hot path; the three resources are released on every path - round-4 advice)
+    struct Probe {
+        float* sink = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Probe() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (sink) (void)hipFree(sink); }
+    } pr;
+    HIPC(hipMalloc((void**)&pr.sink, 4));
+    HIPC(hipEventCreate(&pr.e0)); HIPC(hipEventCreate(&pr.e1));
     const int grid = 2 * num_cus();
     float best = 1e30f;
     for (int r = 0; r < 4; ++r) {                                    // (the first launch warms the clock)
-        HIPC(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(matrix_rate_kernel, dim3(grid), dim3(256), 0, st, iters, random, sink);
-        HIPC(hipEventRecord(e1, st)); HIPC(hipEventSynchronize(e1));
-        float ms = 0.f; HIPC(hipEventElapsedTime(&ms, e0, e1));
+        HIPC(hipEventRecord(pr.e0, st));
+        hipLaunchKernelGGL(matrix_rate_kernel, dim3(grid), dim3(256), 0, st, iters, random, pr.sink);
+        HIPC(hipEventRecord(pr.e1, st)); HIPC(hipEventSynchronize(pr.e1));
+        float ms = 0.f; HIPC(hipEventElapsedTime(&ms, pr.e0, pr.e1));
         if (r && ms < best) best = ms;
     }
-    HIPC(hipEventDestroy(e0)); HIPC(hipEventDestroy(e1));
-    HIPC(hipFree(sink));
     *tflops = 2.0 * 32 * 32 * 16 * 8.0 * iters * 4 * grid / (best * 1e-3) / 1e12;
     API_END
 }

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(256, 2) void matrix_rate_kernel(int iters, int rand
 // Inter-step patch split (utils/util.py:108-146): the reference reflect-pads the canvas and slices one window after the other; here
 // one launch writes the whole window batch out[(w * B + b)][c][y][x] = x[b][c][refl(h0_w + y - pd)][refl(w0_w + x - pd)] straight from
 // the un-padded canvas (no padded copy, no per-window cat).  win = [nwin][2] (h0, w0) in padded coordinates; reflect without the
-// edge pixel (torch 'reflect').  grid (ceil(skip / 64) * skip, C, nwin * B), 64 threads x 4 columns... plain 1-D rows of 256 columns per block.
+// edge pixel (torch 'reflect').  grid (ceil(skip / 256) * skip, C, nwin * B), 256 threads: one block = 256 columns of one window row.  The host validates the window
+// list before it is uploaded (ucdir_amd/patch.py); the reflected index is clamped into the canvas all the same, so a bad entry can never read out of bounds.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ x, int B, int C, int H, int W, int pd, const int* __restrict__ win,
                                                              int skip, float* __restrict__ out) {
@@ -670,5 +671,7 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
     int sy = win[2 * w] + y - pd, sx = win[2 * w + 1] + xx - pd;
     sy = sy < 0 ? -sy : (sy >= H ? 2 * H - 2 - sy : sy);
     sx = sx < 0 ? -sx : (sx >= W ? 2 * W - 2 - sx : sx);
+    sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+    sx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
     out[(((long long)wb * C + c) * skip + y) * skip + xx] = x[(((long long)b * C + c) * H + sy) * W + sx];
 }

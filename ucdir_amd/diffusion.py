@@ -178,8 +178,16 @@ class GaussianDiffusion(nn.Module):
         x = x_in.contiguous().float()
         sample_inter = 1 | (self.num_timesteps // 10)
         self._begin()
+        try:                                                  # entered at once: nothing between _begin and the finally may raise past _end (round-4 advice)
+            ret = self._p_sample_steps(x, kwargs.get("guide"), sample_inter)
+        finally:
+            self._end()                                       # padded guide windows / gather buffers of this restoration
+        if continous:
+            return torch.cat(ret, dim=0)
+        return ret[-1]
+
+    def _p_sample_steps(self, x, guide, sample_inter):
         self._start_noise(x.device, kernel_rng=True)
-        guide = kwargs.get("guide")
         B = x.shape[0]
         if getattr(self.denoise_fn, "use_graph", False) and self._small(x):
             # graph replay: the four tensors the denoiser sees live in buffers that persist ACROSS restorations of the
@@ -206,25 +214,20 @@ class GaussianDiffusion(nn.Module):
             lvl = torch.empty((B, 1), dtype=torch.float32, device=x.device)
         ret = [x]
         k = 1
-        try:
-            for i in reversed(range(self.num_timesteps)):
-                level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
-                lvl.fill_(level)
-                eps = self._eps(cond, img, lvl, guide, out=eps_buf)
-                if self.noise_source is not None:
-                    noise = self._noise(img, k) if i > 0 else None
-                    sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
-                else:                                             # noise of (seed, step k, element) generated in the update kernel
-                    sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
-                if i > 0:
-                    k += 1
-                if i % sample_inter == 0:
-                    ret.append(img.clone())
-        finally:
-            self._end()                                       # padded guide windows / gather buffers of this restoration
-        if continous:
-            return torch.cat(ret, dim=0)
-        return ret[-1]
+        for i in reversed(range(self.num_timesteps)):
+            level, c_recip, c_recipm1, coef1, coef2, sigma = self.step_coefficients(i)
+            lvl.fill_(level)
+            eps = self._eps(cond, img, lvl, guide, out=eps_buf)
+            if self.noise_source is not None:
+                noise = self._noise(img, k) if i > 0 else None
+                sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
+            else:                                             # noise of (seed, step k, element) generated in the update kernel
+                sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
+            if i > 0:
+                k += 1
+            if i % sample_inter == 0:
+                ret.append(img.clone())
+        return ret
 
     @torch.no_grad()
     def ddim_sample(self, x_in, continous=False, kwargs={}, sampling_timesteps=5, eta=1.0):
@@ -236,13 +239,11 @@ class GaussianDiffusion(nn.Module):
         pairs = list(zip(times[:-1], times[1:]))
         ac = self._host_tables["alphas_cumprod"]
         self._begin()
-        self._start_noise(x_in.device)
-        img = self._noise(x_in, 0)
-        imgs = [img]
-        guide = kwargs.get("guide")
-        k = 1
         try:
-            img = self._ddim_steps(x_in, img, imgs, pairs, ac, guide, eta, k)
+            self._start_noise(x_in.device)
+            img = self._noise(x_in, 0)
+            imgs = [img]
+            img = self._ddim_steps(x_in, img, imgs, pairs, ac, kwargs.get("guide"), eta, 1)
         finally:
             self._end()
         return img if not continous else torch.stack(imgs, dim=1)
@@ -281,8 +282,8 @@ class GaussianDiffusion(nn.Module):
             return self._eps(x_in, x, lvl, guide)
 
         self._begin()
-        self._start_noise(x_in.device)
         try:
+            self._start_noise(x_in.device)
             return D.sample(model_eps, ns, self._noise(x_in, 0), steps=steps, order=order)
         finally:
             self._end()

@@ -8,6 +8,14 @@ import torch
 import torch.nn.functional as F
 
 
+def _check_windows(wins, Hp, Wp, skip):
+    """The gather kernel trusts the device-side (h0, w0) list (round-4 advice): every window is skip x skip and lies inside the
+    padded canvas, or the call is refused before anything is uploaded."""
+    for (a, b, c, d) in wins:
+        if not (b - a == skip and d - c == skip and 0 <= a and b <= Hp and 0 <= c and d <= Wp):
+            raise ValueError(f"patch window {(a, b, c, d)} is not a {skip} x {skip} window of the {Hp} x {Wp} padded canvas")
+
+
 def patch_windows(H, W, skip, padding):
     """Window list of utils/util.py:119-137 for a padded canvas H x W, in evaluation order."""
     shift = skip - 2 * padding
@@ -96,6 +104,7 @@ def patch_forward_guide(noisy, net, params, skip=512, padding=32, group=None, ma
                 wkey = ("win", tuple(chunk), noisy.device)
                 wd = cache.get(wkey)
                 if wd is None:                                       # (h0, w0) of the chunk's windows on the device: once per restoration
+                    _check_windows(chunk, noisy.shape[-2] + 2 * pd, noisy.shape[-1] + 2 * pd, skip)
                     wd = torch.tensor([[a, c] for (a, b, c, d) in chunk], dtype=torch.int32, device=noisy.device)
                     cache[wkey] = wd
                 xb = gather_windows(noisy, pd, wd, skip)
