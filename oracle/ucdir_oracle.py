@@ -267,9 +267,10 @@ def _fold_conv(xb, mean, rstd, w, bias, gamma, beta, rnd, groups=1):
 
 
 def resblock_dy3h_emu(sd: SD, p: str, srcs: Sequence[torch.Tensor], temb: torch.Tensor, guide: torch.Tensor, rnd: bool,
-                      taps: Optional[dict] = None) -> torch.Tensor:
+                      taps: Optional[dict] = None, force: Optional[dict] = None) -> torch.Tensor:
     """ResnetBlockDY3h.forward (model/ucdir.py:122-140) with the engine's rounding points.  ``srcs``: the fp32 (pre-rounding)
-    tensors whose channel concatenation is the block's input.  Returns the fp32 value the engine rounds on store."""
+    tensors whose channel concatenation is the block's input.  Returns the fp32 value the engine rounds on store.
+    ``force``: see dy3h_naive_forward_emu (here: the stored h1 the second half of the block continues from)."""
     B, _, H, W = srcs[0].shape
     xb = torch.cat([_rb(t, rnd) for t in srcs], dim=1)
     attw = time_weights(sd, p, temb)
@@ -277,6 +278,8 @@ def resblock_dy3h_emu(sd: SD, p: str, srcs: Sequence[torch.Tensor], temb: torch.
     h1 = swish(_fold_conv(xb, mean, rstd, sd[p + "conv1.weight"], sd[p + "conv1.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"], rnd))
     if taps is not None:
         taps[p + "h1"] = h1
+    if force is not None and (p + "h1") in force:
+        h1 = force[p + "h1"]
     m2, r2 = _mean_rstd([h1])
     att_sp = guide_branch(sd, p, guide, W) * attw.view(B, -1, 1, 1)
     nset = att_sp.shape[1]
@@ -323,38 +326,41 @@ def _upconv_emu(xb: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, rnd: bool
 
 
 def dy3h_naive_forward_emu(sd: SD, x: torch.Tensor, level: torch.Tensor, guide: torch.Tensor, prefix: str = "denoise_fn.",
-                           taps: Optional[dict] = None, rnd: bool = True) -> torch.Tensor:
+                           taps: Optional[dict] = None, rnd: bool = True, force: Optional[dict] = None) -> torch.Tensor:
     """DY3h.naiveforward (model/ucdir.py:270-293) with bf16 rounding where ucdir_amd/csrc rounds (``rnd=False``: no rounding,
-    equal to dy3h_naive_forward up to fp32 re-association)."""
+    equal to dy3h_naive_forward up to fp32 re-association).
+    ``force`` (teacher forcing, for per-layer checks): {tap name: tensor}.  After a layer's own output has been recorded in ``taps``,
+    the network CONTINUES from ``force[name]`` (the activation another implementation stored for that layer) instead of its own
+    value - every layer is then evaluated on the other implementation's inputs, and what is left between the two per layer is
+    summation order and single rounding flips, not the chaotic growth of two realisations of the rounding noise over 61 GroupNorms."""
     temb = noise_embedding(sd, level, prefix)
     downs, mid, ups = _layer_plan(sd, prefix)
     feats = []
 
+    def forced(name, y):
+        if taps is not None:
+            taps[name] = y
+        return force[name] if (force is not None and name in force) else y
+
     def run_block(base, srcs):
-        y = resblock_dy3h_emu(sd, base + "res_block.", srcs, temb, guide, rnd, taps)
+        y = resblock_dy3h_emu(sd, base + "res_block.", srcs, temb, guide, rnd, taps, force)
         if (base + "attn.qkv.weight") in sd:
             y = self_attention_emu(sd, base + "attn.", y, rnd)
-        if taps is not None:
-            taps[base[:-1]] = y
-        return y
+        return forced(base[:-1], y)
 
     for kind, base in downs:
         if kind == "stem":
-            x = F.conv2d(_rb(x, rnd), _rb(sd[base + "weight"], rnd), sd[base + "bias"], padding=1)
+            x = forced(base[:-1], F.conv2d(_rb(x, rnd), _rb(sd[base + "weight"], rnd), sd[base + "bias"], padding=1))
         elif kind == "resample":
-            x = F.conv2d(_rb(x, rnd), _rb(sd[base + "conv.weight"], rnd), sd[base + "conv.bias"], stride=2, padding=1)
+            x = forced(base[:-1], F.conv2d(_rb(x, rnd), _rb(sd[base + "conv.weight"], rnd), sd[base + "conv.bias"], stride=2, padding=1))
         else:
             x = run_block(base, [x])
-        if taps is not None and kind != "block":
-            taps[base[:-1]] = x
         feats.append(x)
     for kind, base in mid:
         x = run_block(base, [x])
     for kind, base in ups:
         if kind == "resample":
-            x = _upconv_emu(_rb(x, rnd), sd[base + "conv.weight"], sd[base + "conv.bias"], rnd)
-            if taps is not None:
-                taps[base[:-1]] = x
+            x = forced(base[:-1], _upconv_emu(_rb(x, rnd), sd[base + "conv.weight"], sd[base + "conv.bias"], rnd))
         else:
             x = run_block(base, [x, feats.pop()])
     mean, rstd = _mean_rstd([x])

@@ -253,6 +253,37 @@ def forward_case(cfg: UNetConfig, B, H, W, levels, seed=11, taps=False, net_sd=N
     return out, eps.cpu(), ref
 
 
+def layerwise_emu_case(cfg: UNetConfig, B, H, W, levels, seed=11, net_sd=None):
+    """Every layer of a HIP forward against the oracle's bf16-emulation mode evaluated ON THE HIP PATH'S OWN INPUTS (teacher
+    forcing: oracle.dy3h_naive_forward_emu(force=...)): per layer {name: metrics(HIP stored activation, bf16(emulated layer
+    output))}, plus 'eps' = the final conv on the HIP path's last activation.  Two realisations of the rounding noise decorrelate
+    over the depth of the network (HIP vs emulation end to end: 1.2e-2, like HIP vs the fp32 oracle); layer by layer on identical
+    inputs they differ by summation order only, so a systematic error of a few 1e-3 in ANY single layer shows."""
+    net, sd = net_sd if net_sd is not None else build_net(cfg)
+    cond, guide, x_t = map(torch.from_numpy, synth_inputs(B, H, W, seed=seed))
+    lvl = torch.tensor(levels, dtype=torch.float32).view(B, 1)
+    x6 = torch.cat([cond, x_t], 1)
+    with torch.no_grad():
+        eps = net.denoise_fn(x6.to(DEV), lvl.to(DEV), guide.to(DEV))
+    torch.cuda.synchronize()
+    from ucdir_amd.spec import unet_layers
+    force = {}
+    for Ld in unet_layers(cfg):
+        key = "denoise_fn." + Ld.name
+        force[key] = net.denoise_fn.debug_read(Ld.name, "out").float().cpu()
+        if Ld.kind == "block":
+            force[key + ".res_block.h1"] = net.denoise_fn.debug_read(Ld.name, "h1").float().cpu()
+    torch.cuda.synchronize()
+    ph, pw = O.pad32(H), O.pad32(W)
+    etaps = {}
+    e = O.dy3h_naive_forward_emu(sd, F.pad(x6, (0, pw, 0, ph), mode="reflect"), lvl, F.pad(guide, (0, pw, 0, ph), mode="reflect"),
+                                 taps=etaps, force=force)[..., :-ph, :-pw]
+    out = {"eps": metrics(eps, e)}
+    for k, v in force.items():
+        out[k[len("denoise_fn."):]] = metrics(v, etaps[k].to(torch.bfloat16).float())
+    return out
+
+
 def conv_stats_case(B, H, W, cin, cout, ksize, mode, gn, runs=3, seed=0):
     """GroupNorm statistics a conv launch accumulates for its OUTPUT (fixed-point atomics) against float64 sums of the
     output it stored, and their run-to-run reproducibility.  A size-independent property: usable at bench size."""

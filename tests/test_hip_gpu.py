@@ -430,6 +430,51 @@ def test_forward_bit_reproducible_at_bench_size(sid_net):
 
 
 
+EMU_LAYER_TOL = 2e-3   # one layer of the HIP path against the oracle's bf16-emulation mode ON THE SAME INPUTS (teacher forcing): what is left is
+                       # fp32 summation order and single bf16 rounding flips.  Measured (tools/_emu_probe.py): worst layer 6.7e-4 (full SID, B = 1),
+                       # 4.4e-4 (B = 4), 8.9e-4 (small configuration) - the attention blocks of the 18^2 / 36^2 levels; everything else <= 4e-4
+
+
+@pytest.mark.parametrize("B", [1, 4, 16])
+def test_full_sid_forward_layer_by_layer_vs_bf16_emulation(sid_net, B):
+    """The second oracle mode (round-4 verdict).  End to end the emulation is one more realisation of the rounding noise: it sits
+    1.50e-2 from the fp32 oracle - exactly where the HIP path sits (1.47 - 1.50e-2), which shows that the whole build-vs-oracle error IS
+    the numerics plan - and 1.2e-2 from the HIP path, so end to end it is no tighter a net than FWD_TOL.  Layer by layer on identical
+    inputs it is: every stored activation (36 layer outputs + 27 h1 tensors) of a full SID forward against the emulated layer fed with
+    the HIP path's own input activations must agree to EMU_LAYER_TOL, an order of magnitude below FWD_TOL - a systematic error of a
+    few 1e-3 in any single kernel shows.  B = 1: the one-shot / split-K kernels; B = 4, 16: the persistent kernels and conv_sk
+    (B = 16: the dispatch bench.py times; samples 0 and 15 are checked)."""
+    if B == 16:
+        # the CPU emulation of 16 samples would take minutes: check the batch's first and last sample through B = 16 HIP forwards
+        net, sd = sid_net
+        from ucdir_amd.weights import synth_inputs
+        import torch.nn.functional as F
+        from ucdir_amd.spec import unet_layers
+        cond, guide, x_t = map(torch.from_numpy, synth_inputs(16, 256, 256, seed=41))
+        lvl = torch.linspace(0.02, 0.97, 16).reshape(16, 1)
+        x6 = torch.cat([cond, x_t], 1)
+        with torch.no_grad():
+            net.denoise_fn(x6.cuda(), lvl.cuda(), guide.cuda())
+        torch.cuda.synchronize()
+        force = {}
+        for Ld in unet_layers(SID):
+            key = "denoise_fn." + Ld.name
+            force[key] = net.denoise_fn.debug_read(Ld.name, "out").float().cpu()[[0, 15]]
+            if Ld.kind == "block":
+                force[key + ".res_block.h1"] = net.denoise_fn.debug_read(Ld.name, "h1").float().cpu()[[0, 15]]
+        etaps = {}
+        O.dy3h_naive_forward_emu(sd, F.pad(x6[[0, 15]], (0, 32, 0, 32), mode="reflect"), lvl[[0, 15]],
+                                 F.pad(guide[[0, 15]], (0, 32, 0, 32), mode="reflect"), taps=etaps, force=force)
+        out = {k: C.metrics(v, etaps[k].to(torch.bfloat16).float()) for k, v in force.items()}
+    else:
+        out = C.layerwise_emu_case(SID, B, 256, 256, [0.4, 0.003, 0.8, 0.95][:B], seed=31, net_sd=sid_net)
+    worst = max(out, key=lambda k: out[k]["rel_rms"])
+    print(f"B = {B}: {len(out)} activations, worst {worst}: {out[worst]}")
+    assert len(out) >= 36 + 27                  # 36 layer outputs (stem, 27 blocks, 4 + 4 resamplers) + 27 h1 tensors (+ eps)
+    for k, m in out.items():
+        assert not m["nan"] and m["rel_rms"] < EMU_LAYER_TOL, (k, m)
+
+
 @pytest.mark.parametrize("B", [8, 16])
 def test_forward_bench_dispatch_vs_oracle_and_reference(golden_dir, sid_net, B):
     """The dispatch bench.py times (B = 16 at 256^2; B = 8 engages the same persistent kernels) against the oracle AND the

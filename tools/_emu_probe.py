@@ -5,12 +5,9 @@ import torch, hip_checks as C
 from ucdir_amd.spec import UNetConfig
 SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, attn_res=(16,), image_size=128)
 SMALL = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4), res_blocks=1, attn_res=(32,), image_size=128)
-for cfg, name, H in ((SMALL, "small", 64), (SID, "sid", 256)):
+for cfg, name, H, B in ((SMALL, "small", 64, 2), (SID, "sid", 256, 1), (SID, "sid", 256, 4)):
     net_sd = C.build_net(cfg)
-    for seed, lv in ((31, 0.4), (21, 0.0029)):
-        out, eps, ref = C.forward_case(cfg, 1, H, H, [lv], seed=seed, taps=True, net_sd=net_sd, emu=True)
-        print(name, seed, lv, "eps vs oracle %.3e  eps vs emu %.3e  emu vs oracle %.3e" % (out["eps"]["rel_rms"], out["eps_emu"]["rel_rms"], out["emu_vs_oracle"]["rel_rms"]))
-        for k, v in out.items():
-            if k.endswith("@emu"):
-                base = k[:-4]
-                print("   %-28s vs oracle %.3e   vs emu %.3e" % (base, out[base]["rel_rms"], v["rel_rms"]))
+    out = C.layerwise_emu_case(cfg, B, H, H, [0.4, 0.003, 0.8, 0.95][:B], seed=31, net_sd=net_sd)
+    print(name, B, "worst layer %.3e" % max(v["rel_rms"] for v in out.values()))
+    for k, v in out.items():
+        print("   %-28s rel_rms %.3e  max_abs %.3e" % (k, v["rel_rms"], v["max_abs"]))

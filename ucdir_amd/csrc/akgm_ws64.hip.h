@@ -45,7 +45,7 @@ __device__ __forceinline__ void w64_dma16(const void* sbase, unsigned voff, unsi
 // NPT = pixel tiles per tile (2 | 4: 64 | 128 positions); NW = waves per workgroup (8: half a group per workgroup, one workgroup per CU;
 // 4: a QUARTER group - 16 features x 8 sets = 128 rows - per workgroup, 80 KB of LDS: TWO independent workgroups per CU, so the two waves
 // of a SIMD belong to different workgroups and no barrier aligns them).  p.tiles_x = tiles per sample, p.tiles_y unused (1), p.tw = halo bytes
-template <int NPT, int NW>
+template <int NPT, int NW, bool ASYM = false>
 __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
     using L = AkWs64<NW>;
     constexpr int NK = L::NK;
@@ -53,6 +53,11 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
     constexpr int NPX = 32 * NPT;
     constexpr int FEAT = 4 * NW;                                   // output features of the workgroup
     constexpr int PP = 1024 / L::SEGB;                             // positions per residual / output piece of 1 KB
+    // ASYM (NW = 8): ALL the memory chores of a tile - the LDS-DMAs of the next tile, the stores of the previous one - are done by waves 0 - 3.
+    // The matrix pipe of a SIMD goes to its OLDER wave whenever both have an MFMA ready (tools/micro/mfma_arb.hip): waves 0 - 3 run their K
+    // loops unimpeded and then wait at the tile barrier, waves 4 - 7 only get the pipe while their partner is outside its K loops.  With the
+    // chores on the older half, the younger half starts its first K loop right behind the barrier, under the partner's chores.
+    constexpr int NDW = ASYM ? 4 : NW;                             // waves that do the chores
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
     // halo piece k (8 positions x 128 B): wave w stages pieces w, w + NW, ...; lane -> (halo position 8 k + lane / 8, physical chunk lane & 7);
     // the logical chunk is physical ^ (position >> 1) & 7 = physical ^ (4 (k & 1) + lane / 16)
     const int npiece = (NPX + 2 * Wp + 2 + 7) >> 3;
-    constexpr int NHOP = (L::HPOS / 8 + NW - 1) / NW;              // halo DMA operations per wave at most (5 | 9)
+    constexpr int NHOP = (L::HPOS / 8 + NDW - 1) / NDW;            // halo DMA operations per (chore) wave at most (5 | 9)
+    constexpr int NROP = NW / NDW;                                 // residual pieces per chore wave
     // B fragment of tap t, channel quarter 0, pixel tile 0, buffer 0: LDS byte address (quarter cq: ^ (cq << 5); pixel tile q: + q PSTEP)
     unsigned bt[9];
 #pragma unroll
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
     const unsigned st_lane = OFF_STAGE + l31 * L::SEGB + (((wave >> 1) ^ ((l31 >> 2) & (L::CPS - 1))) << 4) + 8 * (wave & 1) + 4 * hh;   // + 32 SEGB q
 
     int b = t_beg / tps, ti = t_beg - b * tps;                      // tile t = (sample b, tile ti of the sample)
-    // DMA operation `op` of tile (nb, nti) into buffer buf: 0 .. NHOP - 1 = this wave's halo pieces NW op + w, NHOP = its guide piece (32
-    // positions x 32 B, waves < NPT), NHOP + 1 = its residual piece (PP positions x SEGB, pieces < NPX / PP)
+    // DMA operation `op` of tile (nb, nti) into buffer buf: 0 .. NHOP - 1 = this wave's halo pieces NDW op + w, NHOP = its guide piece (32
+    // positions x 32 B, waves < NPT), NHOP + 1 + rk = its residual pieces NDW rk + w (PP positions x SEGB, pieces < NPX / PP)
     auto dma_op = [&](auto opc, int nb, int nti, int buf) {
         constexpr int op = decltype(opc)::value;
         // the per-lane offsets are formed HERE (three or four VALU per piece), from a lane id that is opaque at this point: hoisted to
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
         unsigned ln = lane;
         asm volatile("" : "+v"(ln));
         if constexpr (op < NHOP) {
-            const int k = op * NW + wave;
+            const int k = op * NDW + wave;
             if (k < npiece) {
                 int sp = nti * NPX + 8 * k + (int)(ln >> 3);
                 sp = sp < Ptot ? sp : Ptot - 1;                     // (the last tile's halo may run past the sample: clamped, feeds dropped positions only)
@@ -140,15 +146,18 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
                           (unsigned)__builtin_amdgcn_readfirstlane(OFF_ATT + buf * L::ATT + wave * 1024));
             }
         } else {
-            if (wave < NPX / PP) {
-                const unsigned pos = PP * wave + ln / L::CPS;
+            constexpr int rk = op - NHOP - 1;                       // this wave's residual piece rk: piece NDW rk + w
+            const int piece = NDW * rk + wave;
+            if (piece < NPX / PP) {
+                const unsigned pos = PP * piece + ln / L::CPS;
                 int P = Wp + 1 + nti * NPX + (int)pos; P = P < Ptot ? P : Ptot - 1;
                 const unsigned off = (unsigned)P * (CPX * 2) + (unsigned)(chan0 + (((ln & (L::CPS - 1)) ^ ((pos >> 2) & (L::CPS - 1))) << 3)) * 2;
-                w64_dma16(p.res + (long long)nb * p.res_bstride, off, (unsigned)__builtin_amdgcn_readfirstlane(OFF_STAGE + buf * L::STAGE + wave * 1024));
+                w64_dma16(p.res + (long long)nb * p.res_bstride, off, (unsigned)__builtin_amdgcn_readfirstlane(OFF_STAGE + buf * L::STAGE + piece * 1024));
             }
         }
     };
-    static_for<0, NHOP + 2>([&](auto opc) { dma_op(opc, b, ti, 0); });
+    constexpr int NOPS = NHOP + 1 + NROP;
+    if (wave < NDW) static_for<0, NOPS>([&](auto opc) { dma_op(opc, b, ti, 0); });
 
     int b_cur = -1;
     float rstd = 1.f, aw[8];
@@ -156,7 +165,9 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
     for (int s = 0; s < 8; ++s) aw[s] = 0.f;
     stat_t S1 = 0, S2 = 0;
     bool have_prev = false;                                          // results of the previous tile wait in its staging slot
-    long long prev_out = 0;
+    long long prev_out[NROP];
+#pragma unroll
+    for (int i = 0; i < NROP; ++i) prev_out[i] = -1;
 
 #pragma unroll 1
     for (int t = t_beg; t <= t_end; ++t) {
@@ -166,15 +177,18 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
         W64_STAMP();                                                // tile top
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         W64_STAMP();                                                // behind the barrier
-        if (have_prev) {                                            // the previous tile's finished segments out
+        if (have_prev && wave < NDW) {                              // the previous tile's finished segments out
+#pragma unroll
+            for (int i = 0; i < NROP; ++i) {
 #ifndef W64_ABL_NOSTORE
-            if (prev_out >= 0)
+                if (prev_out[i] >= 0)
 #else
-            if (prev_out == -12345)
+                if (prev_out[i] == -12345)
 #endif
-            {
-                const u32x4_t ln = *reinterpret_cast<const u32x4_t*>(smem + OFF_STAGE + (buf ^ 1) * L::STAGE + tid * 16);
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(p.out) + prev_out) = ln;
+                {
+                    const u32x4_t ln = *reinterpret_cast<const u32x4_t*>(smem + OFF_STAGE + (buf ^ 1) * L::STAGE + (i * 64 * NDW + tid) * 16);
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(p.out) + prev_out[i]) = ln;
+                }
             }
         }
         if (t == t_end) break;
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W64_STAMP();                                                // stores issued
 #ifndef W64_ABL_NODMA
-        if (!last) static_for<0, NHOP + 2>([&](auto opc) { dma_op(opc, nb, nti, buf ^ 1); });
+        if (!last && wave < NDW) static_for<0, NOPS>([&](auto opc) { dma_op(opc, nb, nti, buf ^ 1); });
 #endif
 
         const int P0 = Wp + 1 + ti * NPX;
@@ -221,6 +235,9 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll 1
         for (int qp = 0; qp < NPT; qp += 2) {                       // two pixel tiles at a time
+            // accumulators start at the fold constants of each position's border class.  (Rotating this block behind the previous pair's
+            // epilogue - so that the younger wave of a SIMD enters its first K loop sooner behind the tile barrier - was measured: with the
+            // accumulators live across the tile top hipcc spills all 32 of them; with only the class addresses carried 92.4 -> 97.6 us.)
             f32x16_t acc[2];
             bool valid[2];
 #pragma unroll
@@ -300,11 +317,14 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
         for (int k = 0; k < 9; ++k) bt[k] -= NPT * L::PSTEP;
         S1 += stat_fx((double)s1); S2 += stat_fx((double)s2);
         have_prev = true;
-        {
-            const int mpos = tid / L::CPS, P = P0 + mpos;
-            const int y = fdiv_small(P < Ptot ? P : Ptot - 1, inv_wp), x = P - y * Wp;
-            const bool ok = mpos < NPX && x >= 1 && x <= p.W && P <= Plast;
-            prev_out = ok ? ((long long)b * p.out_bstride + (long long)P * CPX + chan0 + (((tid & (L::CPS - 1)) ^ ((mpos >> 2) & (L::CPS - 1))) << 3)) * 2 : -1;
+        if (wave < NDW) {
+#pragma unroll
+            for (int i = 0; i < NROP; ++i) {                        // line mover items of this thread: the 16 bytes at (i 64 NDW + tid) 16 of the slot
+                const int it = i * 64 * NDW + tid, mpos = it / L::CPS, P = P0 + mpos;
+                const int y = fdiv_small(P < Ptot ? P : Ptot - 1, inv_wp), x = P - y * Wp;
+                const bool ok = mpos < NPX && x >= 1 && x <= p.W && P <= Plast;
+                prev_out[i] = ok ? ((long long)b * p.out_bstride + (long long)P * CPX + chan0 + (((it & (L::CPS - 1)) ^ ((mpos >> 2) & (L::CPS - 1))) << 3)) * 2 : -1;
+            }
         }
         b = nb; ti = nti;
     }

@@ -213,6 +213,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(akgm_ws32_kernel<32>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<16>, AkWs32::LDS); set_lds_attr(akgm_ws32_kernel<8>, AkWs32::LDS);
     set_lds_attr(akgm_ws64_kernel<2, 4>, 160 * 1024); set_lds_attr(akgm_ws64_kernel<4, 4>, 160 * 1024);
     set_lds_attr(akgm_ws64_kernel<2, 8>, 160 * 1024); set_lds_attr(akgm_ws64_kernel<4, 8>, 160 * 1024);
+    set_lds_attr(akgm_ws64_kernel<2, 8, true>, 160 * 1024); set_lds_attr(akgm_ws64_kernel<4, 8, true>, 160 * 1024);
     set_lds_attr(qkv_ws_kernel<256>, QkvWs::LDS); set_lds_attr(qkv_ws_kernel<512>, QkvWs::LDS);
     set_lds_attr(conv_ws_kernel, CvWs::LDS);
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
@@ -811,12 +812,13 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     const bool ws32 = use_ws && use_ws32 && w.Aws32 != nullptr && (w.cg == 32 || (wsb_all && (w.cg == 16 || w.cg == 8))) && w.C == 8 * w.cg && th32 > 0 && y.W % 8 == 0 &&
                       (g_persist_grid > 0 || (long long)y.B * (y.H / th32) * (y.W / 8) * nb32 >= 4LL * num_cus());
     if (ws32) { p.A = w.Aws32; p.th = th32; p.tw = 8; p.tiles_x = y.W / 8; p.tiles_y = y.H / th32; }
-    // 64 channels per group (C = 512: the 36^2 / 18^2 levels), akgm_ws64.hip.h: a QUARTER group per workgroup of four waves, two
-    // independent workgroups per CU (UCDIR_WS64_NW=8: half a group per workgroup of eight waves, one per CU), linear tiles of 64 | 128
-    // positions of the zero-bordered plane; roles x (resident workgroups / roles) tile ranges.  From two tiles per range on (B = 1 keeps the
-    // one-shot kernel and its unit split); UCDIR_NO_WS64 falls back to akgm_halo_stage_kernel
+    // 64 channels per group (C = 512: the 36^2 / 18^2 levels), akgm_ws64.hip.h: half a group per workgroup of eight waves, one per CU, the tile's
+    // memory chores on waves 0 - 3 (UCDIR_WS64_SYM=1: split over all eight; UCDIR_WS64_NW=4: a quarter group per workgroup of four waves, two
+    // independent workgroups per CU); linear tiles of 64 | 128 positions of the zero-bordered plane; roles x (resident workgroups / roles) tile
+    // ranges.  From two tiles per range on (B = 1 keeps the one-shot kernel and its unit split); UCDIR_NO_WS64 falls back to akgm_halo_stage_kernel
     static const bool use_ws64 = !getenv("UCDIR_NO_WS64");
-    static const int ws64_nw = (getenv("UCDIR_WS64_NW") && atoi(getenv("UCDIR_WS64_NW")) == 8) ? 8 : 4;
+    static const int ws64_nw = (getenv("UCDIR_WS64_NW") && atoi(getenv("UCDIR_WS64_NW")) == 4) ? 4 : 8;
+    static const bool ws64_asym = getenv("UCDIR_WS64_SYM") == nullptr;       // NW = 8: the tile's memory chores on waves 0 - 3 only
     int npt64 = 0, tps64 = 0, grid64 = 0, lds64 = 0;
     if (use_ws && use_ws64 && w.Aws64 != nullptr && w.cg == 64 && w.C == 512 && y.H >= 2 && (y.H + 2) * (y.W + 2) < 32768) {
         const int nrole = 128 / ws64_nw, resident = (ws64_nw == 4 ? 2 : 1) * num_cus();
@@ -841,6 +843,9 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
             if (ws64_nw == 4) {
                 if (npt64 == 4) hipLaunchKernelGGL((akgm_ws64_kernel<4, 4>), dim3(grid64), dim3(256), lds64, st, p);
                 else hipLaunchKernelGGL((akgm_ws64_kernel<2, 4>), dim3(grid64), dim3(256), lds64, st, p);
+            } else if (ws64_asym) {
+                if (npt64 == 4) hipLaunchKernelGGL((akgm_ws64_kernel<4, 8, true>), dim3(grid64), dim3(512), lds64, st, p);
+                else hipLaunchKernelGGL((akgm_ws64_kernel<2, 8, true>), dim3(grid64), dim3(512), lds64, st, p);
             } else {
                 if (npt64 == 4) hipLaunchKernelGGL((akgm_ws64_kernel<4, 8>), dim3(grid64), dim3(512), lds64, st, p);
                 else hipLaunchKernelGGL((akgm_ws64_kernel<2, 8>), dim3(grid64), dim3(512), lds64, st, p);
