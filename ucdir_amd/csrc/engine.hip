@@ -26,6 +26,7 @@
 #include "conv_sk.hip.h"
 #include "conv_ws128.hip.h"
 #include "flash_attn.hip.h"
+#include "flash_attn2.hip.h"
 #include "qkv_ws.hip.h"
 #include "common.h"
 #include "misc.hip.h"
@@ -225,6 +226,10 @@ static void ensure_kernel_attrs() {
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
     set_lds_attr(flash_attn_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn_kernel<3, true>, fa_lds_bytes(384));
     set_lds_attr(flash_attn_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn_kernel<4, true>, fa_lds_bytes(512));
+    set_lds_attr(flash_attn2_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn2_kernel<1, true>, fa_lds_bytes(128));
+    set_lds_attr(flash_attn2_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn2_kernel<2, true>, fa_lds_bytes(256));
+    set_lds_attr(flash_attn2_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn2_kernel<3, true>, fa_lds_bytes(384));
+    set_lds_attr(flash_attn2_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn2_kernel<4, true>, fa_lds_bytes(512));
     done.insert(dev);
 }
 
@@ -942,6 +947,7 @@ struct AttnBufs {
 };
 
 static std::atomic<int> g_flash{-1};          // -1: environment (UCDIR_NO_FLASH), 0 / 1: ucdir_debug_flag("flash", v)
+static std::atomic<int> g_flash2{-1};         // -1: environment (UCDIR_FLASH1), 0: flash_attn_kernel, 1: flash_attn2_kernel (ucdir_debug_flag("flash2", v))
 static bool flash_ok(int C) {
     static const bool env_on = !getenv("UCDIR_NO_FLASH");
     const bool on = g_flash < 0 ? env_on : g_flash != 0;
@@ -1054,8 +1060,25 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         f.dbg = fdbg;
 #endif
         const dim3 grid((unsigned)(B * f.nq));
-        const size_t lds = fa_lds_bytes(C);
+        // flash_attn2_kernel (round 5): the two query halves of a workgroup one phase apart, 32-key tiles, K and V't double-buffered;
+        // UCDIR_FLASH1=1 / ucdir_debug_flag("flash2", 0) selects the round-2 kernel (all eight waves in one phase, 64-key tiles)
+        static const bool flash1_env = getenv("UCDIR_FLASH1") != nullptr;
+        const bool flash2 = g_flash2 < 0 ? !flash1_env : g_flash2 != 0;
+        const size_t lds = flash2 ? fa_lds_bytes(C) : fa_lds_bytes(C);
         auto launch = [&]() {
+            if (flash2) {
+                switch (C / 128 * 2 + (a.half ? 1 : 0)) {
+                    case 2: hipLaunchKernelGGL((flash_attn2_kernel<1, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 3: hipLaunchKernelGGL((flash_attn2_kernel<1, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 4: hipLaunchKernelGGL((flash_attn2_kernel<2, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 5: hipLaunchKernelGGL((flash_attn2_kernel<2, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 6: hipLaunchKernelGGL((flash_attn2_kernel<3, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 7: hipLaunchKernelGGL((flash_attn2_kernel<3, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    case 8: hipLaunchKernelGGL((flash_attn2_kernel<4, false>), grid, dim3(FA_THREADS), lds, st, f); break;
+                    default: hipLaunchKernelGGL((flash_attn2_kernel<4, true>), grid, dim3(FA_THREADS), lds, st, f); break;
+                }
+                return;
+            }
             switch (C / 128 * 2 + (a.half ? 1 : 0)) {
                 case 2: hipLaunchKernelGGL((flash_attn_kernel<1, false>), grid, dim3(FA_THREADS), lds, st, f); break;
                 case 3: hipLaunchKernelGGL((flash_attn_kernel<1, true>), grid, dim3(FA_THREADS), lds, st, f); break;
@@ -1756,7 +1779,8 @@ int32_t ucdir_debug_read(ucdir_ctx* ctx, const char* layer, const char* what, fl
 int32_t ucdir_debug_flag(const char* name, int32_t value) {
     API_BEGIN
     require(name != nullptr, "null argument");
-    if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
+    if (!strcmp(name, "flash2")) g_flash2 = value;       // flash kernel: 1 phase-shifted halves (flash_attn2), 0 round-2 kernel, -1 environment
+    else if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
     else if (!strcmp(name, "wsb")) g_wsb = value;
     else if (!strcmp(name, "convsk")) g_convsk = value;       // stream-K conv: 1 forced at any size, 0 off, -1 environment + work threshold
