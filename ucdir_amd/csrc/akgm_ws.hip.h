@@ -286,12 +286,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
                     tca = tc_lane + (cy * 3 + cx) * 2048;
                 }
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 128 * tm + 16 * g4);   // typed vector load: no vmcnt(0) against the DMA in flight
-                        acc[tm][tp][4 * g4 + 0] = c4[0]; acc[tm][tp][4 * g4 + 1] = c4[1]; acc[tm][tp][4 * g4 + 2] = c4[2]; acc[tm][tp][4 * g4 + 3] = c4[3];
-                    }
+                for (int tm = 0; tm < 2; ++tm) acc[tm][tp] = lds_read_f32x16(smem + tca + 128 * tm);   // typed vector loads (no vmcnt(0) against the DMA in flight), concatenated: no v_mov
             }
             // ---- K loop: 5 steps of two taps x 8 channels; B fragments from the halo, A fragments from registers ------
             // software pipeline by hand: B fragments by inline-asm ds_read_b128 with counted lgkmcnt (hipcc's own bookkeeping put

@@ -198,11 +198,7 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws32_kernel(const AkgmHP p
                     const int cx = (tx == 0 && c == 0) ? 0 : ((tx + 1 == p.tiles_x && c == 7) ? 2 : 1);
                     tca = tc_lane + (cy * 3 + cx) * 1024;
                 }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 16 * g4);
-                    acc[tq][4 * g4 + 0] = c4[0]; acc[tq][4 * g4 + 1] = c4[1]; acc[tq][4 * g4 + 2] = c4[2]; acc[tq][4 * g4 + 3] = c4[3];
-                }
+                acc[tq] = lds_read_f32x16(smem + tca);              // (concatenated reads: no v_mov, asmops.hip.h)
             }
             const unsigned qoff = hb0 + qp * AkWs32::QSTEP;
             // K loop software-pipelined by hand (inline-asm fragment reads, counted lgkmcnt; see akgm_ws.hip.h): the fragments of

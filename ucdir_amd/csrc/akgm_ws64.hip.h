@@ -252,11 +252,7 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[tq][e] = (float)tca;
 #else
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(smem + tca + 16 * g4);
-                    acc[tq][4 * g4 + 0] = c4[0]; acc[tq][4 * g4 + 1] = c4[1]; acc[tq][4 * g4 + 2] = c4[2]; acc[tq][4 * g4 + 3] = c4[3];
-                }
+                acc[tq] = lds_read_f32x16(smem + tca);            // (concatenated reads: no v_mov, asmops.hip.h)
 #endif
             }
             // K loop software-pipelined by hand (inline-asm fragment reads, counted lgkmcnt; see akgm_ws.hip.h): the fragments of

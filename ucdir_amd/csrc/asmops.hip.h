@@ -25,3 +25,13 @@ __device__ __forceinline__ void lgkm_wait_asm() {
 }
 
 
+
+// 16 consecutive floats from LDS as one accumulator tuple: four 16-byte reads CONCATENATED (shufflevector -> REG_SEQUENCE: the reads land in the
+// tuple's sub-registers).  Element-wise assignment from four f32x4 temporaries cost 16 v_mov per tile in the AKGM kernels' fold-constant start.
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+__device__ __forceinline__ f32x16_t lds_read_f32x16(const unsigned char* p) {
+    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(p), c1 = *reinterpret_cast<const f32x4_t*>(p + 16);
+    const f32x4_t c2 = *reinterpret_cast<const f32x4_t*>(p + 32), c3 = *reinterpret_cast<const f32x4_t*>(p + 48);
+    const f32x8_t lo = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c2, c3, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}

@@ -244,31 +244,32 @@ __global__ __launch_bounds__(HC_THREADS, 2) void conv_ws_kernel(const GemmP p) {
         for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[tp][e] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
-        // software pipeline: the two fragment reads of step j + CW_DEPTH are issued in front of the two MFMAs of step j
-        // (order pinned with sched_group_barrier: left alone, hipcc hoists dozens of reads and spills 67 registers)
-        bf16x8_t bq[CW_DEPTH + 1][2];
-        auto read_b = [&](int j, int slot) {
-            const int tap = j >> 2, c16 = j & 3;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int k2 = c16 ^ (ky == 1 ? 2 : 0);
-            const unsigned a0 = ba[kx][k2] + ky * (CvWs::PITCH * 128);
-            bq[slot][0] = *reinterpret_cast<const bf16x8_t*>(smem + a0);
-            bq[slot][1] = *reinterpret_cast<const bf16x8_t*>(smem + a0 + CvWs::QSTEP);
+        // software pipeline by hand (round 5): inline-asm fragment reads with counted lgkmcnt, the fragments of steps j + 1 and j + 2 in flight
+        // under the two MFMAs of step j.  (Compiler-counted reads, one or two steps ahead, ran the same: hipcc's LDS bookkeeping waits with
+        // lgkmcnt(0) - the read it has just issued included - so the depth never mattered: 109.3 vs 109.5 us in round 3.)
+        bf16x8_t bq[3][2];
+        auto read_b = [&](auto jc, bf16x8_t (&dst)[2]) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int tap = j >> 2, c16 = j & 3;
+            constexpr int ky = tap / 3, kx = tap - 3 * ky;
+            constexpr int k2 = c16 ^ (ky == 1 ? 2 : 0);
+            lds_read16_asm<ky * (CvWs::PITCH * 128)>(dst[0], ba[kx][k2]);
+            lds_read16_asm<ky * (CvWs::PITCH * 128) + CvWs::QSTEP>(dst[1], ba[kx][k2]);
         };
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CW_DEPTH; ++j) read_b(j, j);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * CW_DEPTH, 0);
-#pragma unroll
-        for (int j = 0; j < 36; ++j) {
-            if (j + CW_DEPTH < 36) read_b(j + CW_DEPTH, (j + CW_DEPTH) % (CW_DEPTH + 1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // nothing of the compiler's own is queued behind this
+        read_b(std::integral_constant<int, 0>{}, bq[0]);
+        read_b(std::integral_constant<int, 1>{}, bq[1]);
+        __builtin_amdgcn_s_setprio(1);
+        static_for<0, 36>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 2 < 36) read_b(std::integral_constant<int, j + 2>{}, bq[(j + 2) % 3]);
+            constexpr int younger = (j + 2 < 36) ? 4 : ((j + 1 < 36) ? 2 : 0);
+            lgkm_wait_asm<younger>();
             const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // step 0: C = 0 as an inline constant
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % (CW_DEPTH + 1)][0], j ? acc[0] : zero, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % (CW_DEPTH + 1)][1], j ? acc[1] : zero, 0, 0, 0);
-            if (j + CW_DEPTH < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % 3][0], j ? acc[0] : zero, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bq[j % 3][1], j ? acc[1] : zero, 0, 0, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         CW_STAMP();                                                 // K loop done

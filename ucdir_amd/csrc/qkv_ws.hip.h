@@ -160,21 +160,30 @@ __global__ __launch_bounds__(HC_THREADS, 2) void qkv_ws_kernel(const QkvP p) {
             --ahead;
             issue_next();
             const unsigned bb = gbuf * QkvWs::CHUNK;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            // 16 steps (k step j = s / 2, pixel-tile pair th = s % 2) of {two fragment reads, two MFMAs}.  Inline-asm reads with counted lgkmcnt, the
+            // fragments of steps s + 1 and s + 2 in flight under the MFMAs of step s (round 5: hipcc's own bookkeeping put a full lgkmcnt(0) between
+            // each read pair and its MFMAs - waves waiting 48 %, MFMA busy 26 % in profiles/r04_pmc_sq.csv)
+            bf16x8_t xf[3][2];
+            auto frag = [&](auto sc, bf16x8_t (&dst)[2]) {
+                constexpr int st = decltype(sc)::value, j = st >> 1, th = st & 1;
                 const unsigned fa = bb + (fr0 ^ (32u * j));
+                lds_read16_asm<(2 * th) * 8192>(dst[0], fa);
+                lds_read16_asm<(2 * th + 1) * 8192>(dst[1], fa);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            frag(std::integral_constant<int, 0>{}, xf[0]);
+            frag(std::integral_constant<int, 1>{}, xf[1]);
+            __builtin_amdgcn_s_setprio(1);
+            static_for<0, 16>([&](auto sc) {
+                constexpr int st = decltype(sc)::value, j = st >> 1, th = st & 1;
+                if constexpr (st + 2 < 16) frag(std::integral_constant<int, st + 2>{}, xf[(st + 2) % 3]);
+                constexpr int younger = (st + 2 < 16) ? 4 : ((st + 1 < 16) ? 2 : 0);
+                lgkm_wait_asm<younger>();
 #pragma unroll
-                for (int th = 0; th < 2; ++th) {                    // two pixel tiles at a time: 8 fragment registers, not 16
-                    bf16x8_t xf[2];
-#pragma unroll
-                    for (int tq = 0; tq < 2; ++tq) xf[tq] = *reinterpret_cast<const bf16x8_t*>(smem + fa + (2 * th + tq) * 8192);
-#pragma unroll
-                    for (int tq = 0; tq < 2; ++tq)
-                        acc[2 * th + tq] = VT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[tq], af[8 * c + j], acc[2 * th + tq], 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[8 * c + j], xf[tq], acc[2 * th + tq], 0, 0, 0);
-                }
-            }
+                for (int tq = 0; tq < 2; ++tq)
+                    acc[2 * th + tq] = VT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[st % 3][tq], af[8 * c + j], acc[2 * th + tq], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[8 * c + j], xf[st % 3][tq], acc[2 * th + tq], 0, 0, 0);
+            });
             __builtin_amdgcn_s_setprio(0);
             gbuf = gbuf + 1 == QkvWs::NBUF ? 0 : gbuf + 1;
         }
