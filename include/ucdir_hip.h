@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define UCDIR_ABI_VERSION 3
+/* 4: ucdir_gather_windows and ucdir_matrix_rate joined the interface (round 4); a binding built against version 3 must not load this library
+ * silently (round-4 verdict).  Round 5 added no symbol: new kernels are dispatch changes behind the same entry points (A/B switches: the
+ * environment variables of DESIGN.md and ucdir_debug_flag names "flash2", "persist_grid", ...). */
+#define UCDIR_ABI_VERSION 4
 #define UCDIR_MAX_MULTS 8
 
 typedef struct ucdir_ctx ucdir_ctx;

@@ -3,8 +3,11 @@
 Every function returns a dict of error metrics; thresholds live in the tests.
 Tolerances (stated once): the HIP path computes convolutions / attention with bf16 operands and
 fp32 accumulation and stores activations in bf16, so vs the fp32 oracle we expect
-  * single operator on bf16-representable inputs : rel-RMS <~ 3e-3 (weight + output rounding)
-  * full 61-GroupNorm-deep forward               : rel-RMS 1.0-1.3e-2 measured (1.44e-2 predicted by emulation), bound 1.5e-2
+  * single operator on bf16-representable inputs : rel-RMS <~ 3e-3 (weight + output rounding), bound OP_TOL = 4e-3
+  * full 61-GroupNorm-deep forward               : rel-RMS 1.2e-2 (small configuration) / 1.43-1.51e-2 (full SID) measured; the oracle's
+    bf16-emulation mode (oracle.dy3h_naive_forward_emu: rounding where the kernels round) sits at 1.47-1.50e-2 from the fp32 oracle on the
+    same inputs, i.e. the whole difference IS the numerics plan; bound FWD_TOL = 1.7e-2 (tests/test_hip_gpu.py)
+  * one layer against the emulation on the HIP path's own input activations (layerwise_emu_case): <= 6.7e-4 measured, bound 2e-3
 """
 import ctypes
 import math

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCDIR_LIB") or os.path.join(_HERE, "libucdir_hip.so")   # UCDIR_LIB: A/B-test another build
 MAX_MULTS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class UcdirConfig(Structure):
