@@ -29,6 +29,12 @@ def bench_name(k):
         return "akgm_halo"                          # <true> / <false> instantiations share one bench row
     if "akgm_pre_kernel" in k:
         return "akgm_pre"
+    if "akgm_ws64_kernel" in k:
+        return "akgm_ws64"
+    if "akgm_ws32_kernel" in k:
+        return "akgm_ws32"
+    if "flash_attn2_kernel" in k or "flash_attn_kernel" in k:
+        return "flash_attn<fp16>" if ", true>" in k else "flash_attn<bf16>"
     if "akgm_ws_kernel<16>" in k:
         return "akgm_ws<16>"
     if "akgm_ws_kernel" in k:
