@@ -833,7 +833,11 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
             const int hpos = 32 * cand + 2 * (y.W + 2) + 2;
             if (hpos > AkWs64<4>::HPOS) continue;
             const int tps = (span + 32 * cand - 1) / (32 * cand);
-            if (g_persist_grid > 0 || (long long)y.B * tps >= (cand == 4 ? 4LL : 2LL) * nslots) {
+            // engage from four 128-position tiles per range on; with 64-position tiles when a range has at least 1.5 x the positions of one
+            // tile's halo (measured against akgm_halo_stage, tools/bench_op.py akgm: B = 3 at 36^2 34 vs 39 us, B = 8 at 18^2 24.5 vs 26.1; below that
+            // the one-shot kernel wins: B = 1 at 52^2 - the DDPM.test geometry - 41 vs 25.5 us, B = 2 at 36^2 30 vs 25, B = 1 at 64^2 48 vs 28.5)
+            const bool enough = cand == 4 ? (long long)y.B * tps >= 4LL * nslots : 2LL * y.B * span >= 3LL * nslots * hpos;
+            if (g_persist_grid > 0 || enough) {
                 npt64 = cand; tps64 = tps;
                 lds64 = ws64_nw == 4 ? AkWs64<4>::lds(hpos) : AkWs64<8>::lds(hpos);
                 p.tw = AkWs64<4>::HBYTES(hpos);
