@@ -707,7 +707,8 @@ def test_persistent_kernel_switches_agree_at_a_size_where_they_engage():
     off = {k: "1" for k in ("UCDIR_NO_WS", "UCDIR_NO_WS16", "UCDIR_NO_WS32", "UCDIR_NO_WS64", "UCDIR_NO_CONV_WS", "UCDIR_NO_CONV_WS128",
                             "UCDIR_NO_QKV_WS", "UCDIR_NO_ATILE", "UCDIR_NO_CONV_SK")}
     out = {}
-    for tag, env_extra in (("default", {}), ("oneshot", off)):
+    # ("akgm_tc": the persistent AKGM tails with their fold constants from akgm_tc_kernel launches instead of formed in-kernel, round 5)
+    for tag, env_extra in (("default", {}), ("oneshot", off), ("akgm_tc", {"UCDIR_NO_OWNTC": "1"})):
         env = dict(os.environ); env.update(env_extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py"), "sidb4"], env=env, capture_output=True,
                            text=True, timeout=900)
@@ -719,6 +720,9 @@ def test_persistent_kernel_switches_agree_at_a_size_where_they_engage():
         for b in ("s0", "s3"):
             assert not m[b]["nan"] and m[b]["rel_rms"] < FWD_TOL, (tag, b, m[b])
     assert 113 in out["default"]["keys"] and 23 in out["default"]["keys"] and 24 in out["default"]["keys"], out["default"]["keys"]
+    assert out["akgm_tc"]["keys"] == out["default"]["keys"]              # same kernels; the same arithmetic on the same table entries
+    for b in ("s0", "s3"):
+        assert abs(out["akgm_tc"][b]["rel_rms"] - out["default"][b]["rel_rms"]) < 1e-4 * out["default"][b]["rel_rms"], (out["akgm_tc"][b], out["default"][b])
     assert not any(k in out["oneshot"]["keys"] for k in (113, 114, 115, 116, 23, 24, 105, 125)), out["oneshot"]["keys"]
 
 

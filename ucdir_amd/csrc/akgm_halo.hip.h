@@ -27,6 +27,9 @@ struct AkgmHP {
     bf16_t* out; long long out_bstride;
     stat_t* stats_out;                         // (sum, sum of squares) accumulators of the output (stat_add)
     int usplit;                                // akgm_halo_stage_kernel, 64 per group: the 4 units of a group go to 1 | 2 | 4 workgroups
+    // own_tc (the persistent kernels): no akgm_tc_kernel launch in front - a workgroup entering sample b sums the statistics slots itself and
+    // forms its slice of Tc from the sample-independent tables Tbb = bias + Tb and Tg ([9][8C] each) on the way into LDS (akgm_tc_piece)
+    int own_tc; const float* Tbb; const float* Tgt;
     unsigned long long* dbg;
 };
 
@@ -59,6 +62,12 @@ __global__ void akgm_tc_kernel(const stat_t* __restrict__ stats, double inv_coun
     *reinterpret_cast<float4*>(Tc + ((long long)b * 9 + cls) * n + o) =
         make_float4((bi.x + tb.x) * inv - mean * tg.x, (bi.y + tb.y) * inv - mean * tg.y,
                     (bi.z + tb.z) * inv - mean * tg.z, (bi.w + tb.w) * inv - mean * tg.w);
+}
+
+// 16 bytes of a persistent kernel's Tc slice, the arithmetic of akgm_tc_kernel: rel = float index in the [9][8C] tables, inv = 1 / rstd_b
+__device__ __forceinline__ void akgm_tc_piece(const AkgmHP& p, long long rel, unsigned char* dst, float inv, float mean) {
+    const float4 tb = *reinterpret_cast<const float4*>(p.Tbb + rel), tg = *reinterpret_cast<const float4*>(p.Tgt + rel);
+    *reinterpret_cast<float4*>(dst) = make_float4(tb.x * inv - mean * tg.x, tb.y * inv - mean * tg.y, tb.z * inv - mean * tg.z, tb.w * inv - mean * tg.w);
 }
 
 // ATT_LDS (16 / 32 channels per group: one halo chunk per workgroup, the second halo buffer is free): the per-pixel

@@ -227,18 +227,23 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
             }
             S1 = 0; S2 = 0;
             b_cur = b;
+            float mean_b = 0.f;
+            if (p.own_tc) stat_mean_rstd_wave(p.stats, b, p.inv_count, lane, mean_b, rstd);
+            else rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
+            const float inv_b = 1.0f / rstd;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int pc = i * 8 + wave;
-                if (pc < 18)
-                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + (pc >> 1)) * (512 * NCH) + 512 * ch + (pc & 1) * 256 + lane * 4),
-                                                     (LDS_AS void*)(smem + AkWs::OFF_TCS + pc * 1024), 16, 0, 0);
+                if (pc < 18) {
+                    const long long rel = (long long)(pc >> 1) * (512 * NCH) + 512 * ch + (pc & 1) * 256 + lane * 4;
+                    if (p.own_tc) akgm_tc_piece(p, rel, smem + AkWs::OFF_TCS + pc * 1024 + lane * 16, inv_b, mean_b);
+                    else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + (long long)b * 9 * (512 * NCH) + rel),
+                                                          (LDS_AS void*)(smem + AkWs::OFF_TCS + pc * 1024), 16, 0, 0);
+                }
             }
-            rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
 #pragma unroll
             for (int s = 0; s < 8; ++s) aw[s] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.attw[b * 8 + s])));
-            HC_WAIT(0);
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         const bool interior = ty > 0 && tx > 0 && ty + 1 < p.tiles_y && tx + 1 < p.tiles_x;
         const long long tile_el = (long long)(ty * 16 * p.Wp + tx * 16) * CPX;

@@ -201,21 +201,26 @@ __global__ __launch_bounds__(64 * NW, 2) void akgm_ws64_kernel(const AkgmHP p) {
             b_cur = b;
             // fold table slice [9][32 NW] of this sample: piece pc = classes (NW == 8: pc, 64 lanes x 16 B; NW == 4: 2 pc and 2 pc + 1, 32 lanes each)
             constexpr int NTP = (NW == 8) ? 9 : 5;
+            float mean_b = 0.f;
+            if (p.own_tc) stat_mean_rstd_wave(p.stats, b, p.inv_count, lane, mean_b, rstd);
+            else rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
+            const float inv_b = 1.0f / rstd;
 #pragma unroll
             for (int i = 0; i < (NTP + NW - 1) / NW; ++i) {
                 const int pc = i * NW + wave;
                 if (pc < NTP) {
                     const int cl = (NW == 8) ? pc : 2 * pc + (lane >> 5), e4 = (NW == 8) ? lane : (lane & 31);
-                    if (cl < 9)
-                        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + ((long long)b * 9 + cl) * (8 * CPX) + 8 * chan0 + e4 * 4),
-                                                         (LDS_AS void*)(smem + OFF_TCS + pc * 1024), 16, 0, 0);
+                    if (cl < 9) {
+                        const long long rel = (long long)cl * (8 * CPX) + 8 * chan0 + e4 * 4;
+                        if (p.own_tc) akgm_tc_piece(p, rel, smem + OFF_TCS + pc * 1024 + lane * 16, inv_b, mean_b);
+                        else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.Tc + (long long)b * 9 * (8 * CPX) + rel),
+                                                              (LDS_AS void*)(smem + OFF_TCS + pc * 1024), 16, 0, 0);
+                    }
                 }
             }
-            rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ms[2 * b + 1])));
 #pragma unroll
             for (int s = 0; s < 8; ++s) aw[s] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.attw[b * 8 + s])));
-            HC_WAIT(0);
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         const bool last = t + 1 == t_end;
         int nb = b, nti = ti + 1;

@@ -104,6 +104,15 @@ __device__ __forceinline__ void stat_read(const stat_t* s0, const stat_t* s1, in
     }
     S = stat_val(a); Q = stat_val(q);
 }
+// (mean, rstd) of sample b by ONE WAVE: lane l < 2 SLOTS reads accumulator l (even lanes sums, odd lanes sums of squares); integer sums -
+// the same bits as stat_read's serial order - then mean_rstd on the same two doubles
+__device__ __forceinline__ void stat_mean_rstd_wave(const stat_t* stats, int b, double inv_count, int lane, float& mean, float& rstd) {
+    stat_t v = lane < 2 * UCDIR_STAT_SLOTS ? stats[(long long)b * (2 * UCDIR_STAT_SLOTS) + lane] : 0;
+#pragma unroll
+    for (int off = 2; off < 2 * UCDIR_STAT_SLOTS; off <<= 1) v += __shfl_xor(v, off);
+    const stat_t a = __shfl(v, 0), q = __shfl(v, 1);
+    mean_rstd(stat_val(a), stat_val(q), inv_count, mean, rstd);
+}
 // direct (non-atomic) write of a sample's totals: slot 0 carries them, the other slots are cleared
 __device__ __forceinline__ void stat_store(stat_t* stats, int b, double S, double Q) {
     stat_t* d = stats + (long long)b * UCDIR_STAT_SLOTS * 2;

@@ -113,6 +113,7 @@ struct ConvW {
 };
 struct AkgmW {
     bf16_t* A = nullptr; float* bias = nullptr; float* Tb = nullptr; float* Tg = nullptr;
+    float* Tbb = nullptr;          // [9][8C]: bias + Tb[cls] (the persistent kernels form their Tc slices themselves, AkgmHP::own_tc)
     bf16_t* Apre = nullptr;        // cg 8 / 16: LDS image for akgm_pre.hip.h
     bf16_t* Aws32 = nullptr;       // cg 8 / 16 / 32: A fragments of akgm_ws32_kernel<cg>
     bf16_t* Aws64 = nullptr;       // cg 64 (C = 512): A fragments of akgm_ws64_kernel, one half group per workgroup
@@ -155,6 +156,12 @@ static AkgmW upload_akgm(DevPool& pool, const float* wsp, const float* bsp, cons
     AkgmW W;
     W.A = pool.upload(P.A); W.bias = pool.upload(P.bias); W.Tb = pool.upload(P.Tb); W.Tg = pool.upload(P.Tg);
     W.C = C; W.cg = P.cg; W.Kpad = P.Kpad;
+    {
+        std::vector<float> tbb(P.Tb.size());
+        const size_t n = P.bias.size();
+        for (size_t i = 0; i < tbb.size(); ++i) tbb[i] = P.bias[i % n] + P.Tb[i];      // fp32 add, as akgm_tc_kernel's
+        W.Tbb = pool.upload(tbb);
+    }
     if (P.cg == 8 || P.cg == 16) W.Apre = pool.upload(pack_akgm_pre(wsp, gamma, C));
     if (P.cg == 32 || P.cg == 16 || P.cg == 8) W.Aws32 = pool.upload(pack_akgm_ws32(wsp, gamma, C));
     if (P.cg == 64 && C == 512) W.Aws64 = pool.upload(pack_akgm_ws64(wsp, gamma, C));
@@ -774,7 +781,6 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     require(tcbuf != nullptr, "AKGM: no fold-table scratch");
     const double inv_cnt = 1.0 / ((double)w.C * h1.H * h1.W);
     float* msbuf = tcbuf + (size_t)y.B * 9 * 8 * w.C;                    // (mean, rstd) per sample, behind the table
-    hipLaunchKernelGGL(akgm_tc_kernel, dim3(9 * ((8 * w.C + 1023) / 1024), y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
     AkgmHP p;
     p.A = pre ? w.Apre : w.A; p.Kpad = w.Kpad; p.h = h1.p; p.h_bstride = h1.bstride();
     p.C = w.C; p.cg = w.cg; p.H = y.H; p.W = y.W; p.Wp = y.W + 2;
@@ -847,6 +853,12 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     }
     const bool ws64 = npt64 > 0;
     if (ws64) { p.A = w.Aws64; p.th = npt64; p.tiles_x = tps64; p.tiles_y = 1; }
+    // the persistent kernels form their fold constants themselves (27 launches of ~5 us less per B = 16 forward; UCDIR_NO_OWNTC=1: akgm_tc_kernel for all)
+    static const bool use_owntc = !getenv("UCDIR_NO_OWNTC");
+    p.own_tc = use_owntc && (ws64 || ws32 || ws || ws16) && w.Tbb != nullptr;
+    p.Tbb = w.Tbb; p.Tgt = w.Tg;
+    if (!p.own_tc)
+        hipLaunchKernelGGL(akgm_tc_kernel, dim3(9 * ((8 * w.C + 1023) / 1024), y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
     auto launch = [&]() {
         if (ws64) {
             if (ws64_nw == 4) {
