@@ -1540,11 +1540,12 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         const int C = cur->C, co = c->cfg.out_channel;
         static const bool fused = !getenv("UCDIR_NO_FUSED_FINAL");
         if (fused && c->fin_w) {
-            const dim3 grid((c->Wc + 15) / 16, (c->Hc + 15) / 16, B);
-            const size_t lds = (size_t)324 * 80 + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C;
+            const int tiles = ((c->Wc + 15) / 16) * ((c->Hc + 15) / 16) * B;
+            const dim3 grid(tiles < 3 * num_cus() ? tiles : 3 * num_cus());   // persistent: three resident workgroups per CU walk the tiles
+            const size_t lds = (size_t)324 * 80 + (size_t)9 * (C / 32) * 1024 + (size_t)8 * C + (size_t)8 * B;
             require(lds <= 160 * 1024, "final conv: channel count too large for the fused kernel");
             hipLaunchKernelGGL(final_conv_kernel, grid, dim3(256), lds, st, cur->p, c->Hc, c->Wc, C, cur->stats,
-                               1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b, co, eps, c->H, c->W);
+                               1.0 / ((double)C * c->Hc * c->Wc), c->fin_gamma, c->fin_beta, c->fin_w, c->fin_b, co, eps, c->H, c->W, B);
             HIPC(hipGetLastError());
         } else {
             hipLaunchKernelGGL(gn_silu_kernel, dim3(2048, 1, B), dim3(256), 0, st, cur->p, c->fin_act.p, c->Hc, c->Wc, C,

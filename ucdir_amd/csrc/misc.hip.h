@@ -235,53 +235,75 @@ __global__ __launch_bounds__(256) void gn_silu_kernel(const bf16_t* __restrict__
 // column tiles of v_mfma_f32_16x16x32_bf16 (A = weights, rows >= cout zero; K step = one tap x 32 channels).
 // The weight fragments arrive pre-laid-out ([step][lane][8] bf16, pack_final_frags) and are copied to LDS once.
 // Pixels outside the image contribute 0 (the conv zero-pads the ACTIVATED tensor).
-// grid (ceil(W/16), ceil(H/16), B), block 256, dynamic LDS 324 * 80 + 9 * (C/32) * 1024 + 8C bytes; C % 32 == 0.
+// grid min(tiles, 3 x CUs) persistent workgroups, block 256, dynamic LDS 324 * 80 + 9 * (C/32) * 1024 + 8C + 8B bytes; C % 32 == 0.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restrict__ x, int H, int W, int C,
                                                          const stat_t* __restrict__ stats, double inv_count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const bf16_t* __restrict__ wfrag, const float* __restrict__ bias, int cout,
-                                                         float* __restrict__ out, int crop_h, int crop_w) {
+                                                         float* __restrict__ out, int crop_h, int crop_w, int nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-    const int b = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
     constexpr int RS = 80;                             // LDS row: 32 channels of one halo pixel + 16 B pad
     unsigned char* wl = fsm + 324 * RS;                // weight fragments, all steps
     const int nc32 = C / 32, nstep = 9 * nc32;
+    // PERSISTENT (round 5): a workgroup walks tiles blockIdx.x, + gridDim.x, ... (three resident workgroups per CU); the weight fragments,
+    // the per-sample (mean, rstd) list and - per sample - the scale / shift table are set up once instead of once per 16 x 16 tile
+    // (5,184 workgroups per B = 16 launch each paid a serial statistics read, an 18 KB copy and a table build for 2.3 us of work)
     for (int it = threadIdx.x; it < nstep * 64; it += 256)
         *reinterpret_cast<uint4*>(wl + it * 16) = *reinterpret_cast<const uint4*>(wfrag + (long long)it * 8);
-    float mean, rstd;
-    {
-        double S, Q;
-        stat_read(stats, nullptr, b, S, Q);
-        mean_rstd(S, Q, inv_count, mean, rstd);
-    }
-    const bf16_t* xb = x + (long long)b * (H + 2) * (W + 2) * C;
     float* gb = reinterpret_cast<float*>(wl + nstep * 1024);          // GN as one FMA: scale = rstd*gamma | shift = beta - mean*rstd*gamma
-    for (int i = threadIdx.x; i < C; i += 256) { const float sc = rstd * gamma[i]; gb[i] = sc; gb[C + i] = beta[i] - mean * sc; }
+    float* ms = gb + 2 * C;                                            // [nb][2]
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        double S, Q;
+        float mean, rstd;
+        stat_read(stats, nullptr, i, S, Q);
+        mean_rstd(S, Q, inv_count, mean, rstd);
+        ms[2 * i] = mean; ms[2 * i + 1] = rstd;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 15, kg = lane >> 4;
-    f32x4_t acc[4];
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4, tps = tiles_x * tiles_y, total = nb * tps;
+    int b_cur = -1;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int b = t / tps, r = t - b * tps, ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int x0 = tx * 16, y0 = ty * 16;
+        const bf16_t* xb = x + (long long)b * (H + 2) * (W + 2) * C;
+        // 32 channels per pass keep the halo at 26 KB (three workgroups per CU instead of two at C = 64).
+        // halo staging: 324 pixels x 4 sixteen-byte items = 1296 items, 6 per thread; the items of pass c + 1 are requested in front of the
+        // MFMAs of pass c (their registers are free once pass c is in LDS)
+        uint4 v[6]; int dst[6]; long long src[6];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    // 32 channels per pass keep the halo at 26 KB (three workgroups per CU instead of two at C = 64)
-    for (int c32 = 0; c32 < nc32; ++c32) {
-        __syncthreads();                               // gb ready (first pass) / previous pass done with the halo
-        // halo staging: 324 pixels x 4 sixteen-byte items = 1296 items, 6 per thread, all loads in flight before first use
-        {
-            uint4 v[6]; int dst[6];
+        for (int u = 0; u < 6; ++u) {
+            const int it = threadIdx.x + u * 256;
+            dst[u] = -1; src[u] = 0;
+            if (it < 324 * 4) {
+                const int hp = it >> 2, c = (it & 3) * 8;
+                const int hr = hp / 18, hc = hp - hr * 18;
+                const int gy = y0 + hr - 1, gx = x0 + hc - 1;          // image coordinates of this halo pixel
+                dst[u] = (hp * RS + c * 2) | ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0 : (1 << 30));
+                src[u] = ((long long)(gy + 1) * (W + 2) + gx + 1) * C + c;
+            }
+        }
+        auto request = [&](int c32) {
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int it = threadIdx.x + u * 256;
-                v[u] = make_uint4(0, 0, 0, 0); dst[u] = -1;
-                if (it < 324 * 4) {
-                    const int hp = it >> 2, c = (it & 3) * 8;
-                    const int hr = hp / 18, hc = hp - hr * 18;
-                    const int gy = y0 + hr - 1, gx = x0 + hc - 1;      // image coordinates of this halo pixel
-                    dst[u] = (hp * RS + c * 2) | ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0 : (1 << 30));
-                    if (!(dst[u] >> 30)) v[u] = *reinterpret_cast<const uint4*>(xb + ((long long)(gy + 1) * (W + 2) + gx + 1) * C + c32 * 32 + c);
-                }
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (dst[u] >= 0 && !(dst[u] >> 30)) v[u] = *reinterpret_cast<const uint4*>(xb + src[u] + c32 * 32);
             }
+        };
+        request(0);
+        if (b != b_cur) {                              // (every thread is behind the previous tile's last activation pass: nobody reads gb now)
+            const float mean = ms[2 * b], rstd = ms[2 * b + 1];
+            for (int i = threadIdx.x; i < C; i += 256) { const float sc = rstd * gamma[i]; gb[i] = sc; gb[C + i] = beta[i] - mean * sc; }
+            b_cur = b;
+        }
+        f32x4_t acc[4];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) acc[tq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int c32 = 0; c32 < nc32; ++c32) {
+            __syncthreads();                           // gb ready / previous pass (or tile) done with the halo
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 if (dst[u] < 0) continue;
@@ -297,28 +319,29 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const bf16_t* __restric
                 }
                 *reinterpret_cast<uint4*>(fsm + off) = o;
             }
-        }
-        __syncthreads();
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl + ((tap * nc32 + c32) * 64 + lane) * 16);
+            if (c32 + 1 < nc32) request(c32 + 1);
+            __syncthreads();
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl + ((tap * nc32 + c32) * 64 + lane) * 16);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int hp = (wv * 4 + t + ky) * 18 + col + kx;
-                const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(fsm + hp * RS + kg * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
+                for (int tq = 0; tq < 4; ++tq) {
+                    const int hp = (wv * 4 + tq + ky) * 18 + col + kx;
+                    const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(fsm + hp * RS + kg * 16);
+                    acc[tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[tq], 0, 0, 0);
+                }
             }
         }
-    }
-    if (kg == 0) {                                     // lanes 0..15 hold output rows (channels) 0..3 of their pixel column
-        const int xx = x0 + col;
+        if (kg == 0) {                                 // lanes 0..15 hold output rows (channels) 0..3 of their pixel column
+            const int xx = x0 + col;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int y = y0 + wv * 4 + t;
-            if (y < crop_h && xx < crop_w) {
+            for (int tq = 0; tq < 4; ++tq) {
+                const int y = y0 + wv * 4 + tq;
+                if (y < crop_h && xx < crop_w) {
 #pragma unroll
-                for (int o = 0; o < 4; ++o)
-                    if (o < cout) out[(((long long)b * cout + o) * crop_h + y) * crop_w + xx] = acc[t][o] + bias[o];
+                    for (int o = 0; o < 4; ++o)
+                        if (o < cout) out[(((long long)b * cout + o) * crop_h + y) * crop_w + xx] = acc[tq][o] + bias[o];
+                }
             }
         }
     }
