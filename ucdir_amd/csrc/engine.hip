@@ -1513,8 +1513,9 @@ static void forward(ucdir_ctx* c, const float* cond, const float* xt, const floa
         LayerRT& r = c->rt[li];
         if (d.kind == "stem") {
             const int tx = (c->Wc + 15) / 16, ty = (c->Hc + 15) / 16;
-            hipLaunchKernelGGL((stem_mfma_kernel<6, 0>), dim3(tx * ty, d.cout / 64, B), dim3(256), 0, st, cond, xt, c->H, c->W,
-                               c->Hc, c->Wc, d.cout, tx, w.stem_w, r.out.p, r.out.stats);
+            const int units = tx * ty * (d.cout / 64) * B;
+            hipLaunchKernelGGL((stem_mfma_kernel<6, 0>), dim3(units < 4 * num_cus() ? units : 4 * num_cus()), dim3(256), 0, st, cond, xt, c->H, c->W,
+                               c->Hc, c->Wc, d.cout, tx, w.stem_w, r.out.p, r.out.stats, tx * ty, d.cout / 64, B);
             HIPC(hipGetLastError());
         } else if (d.kind == "down") {
             run_conv(w.conv, *cur, nullptr, r.out, COLS_DOWN, 0, nullptr, true, st);
@@ -2131,8 +2132,9 @@ static void predictor_forward(ucdir_predictor* c, const float* x, float* y, hipS
     auto CV = [&](const std::string& n) -> const ConvW& { return c->conv.at(n); };
     {   // conv1_1 + LeakyReLU, reading NCHW fp32 with the bottom/right reflect pad (model/ucdir.py:354-361)
         const int tx = (c->Wc + 15) / 16, ty = (c->Hc + 15) / 16;
-        hipLaunchKernelGGL((stem_mfma_kernel<3, 2>), dim3(tx * ty, 1, B), dim3(256), 0, st, x, x, c->H, c->W, c->Hc, c->Wc, 64, tx,
-                           c->in_w, A("a1").p, (stat_t*)nullptr);
+        const int units = tx * ty * B;
+        hipLaunchKernelGGL((stem_mfma_kernel<3, 2>), dim3(units < 4 * num_cus() ? units : 4 * num_cus()), dim3(256), 0, st, x, x, c->H, c->W, c->Hc, c->Wc, 64, tx,
+                           c->in_w, A("a1").p, (stat_t*)nullptr, tx * ty, 1, B);
         HIPC(hipGetLastError());
     }
     run_conv(CV("conv1_2"), A("a1"), nullptr, A("c1"), COLS_S1, 2, nullptr, false, st);

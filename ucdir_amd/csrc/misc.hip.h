@@ -73,27 +73,31 @@ __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 
 // 32-pixel MFMA tiles) x 64 channels: 5 steps x 4 MFMAs.  Epilogue: optional LeakyReLU, GroupNorm statistics
 // (stat_add), bf16 NHWC stores through a per-wave LDS tile (16 B per lane, a tile row's 2 KB contiguous).
 // The VALU version of this kernel took 180 us at 288^2 x 16 (v_pk_fma issue bound); this one 60 us + its atomics.
-// grid (tiles_x * tiles_y, C0 / 64, B), block 256
+// grid min(units, 4 x CUs) persistent workgroups over (tile, channel block, sample), block 256
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int ACT>
 __global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const float* __restrict__ cond, const float* __restrict__ xt,
                                                            int H, int W, int Hc, int Wc, int C0, int tiles_x,
                                                            const bf16_t* __restrict__ wfrag,
-                                                           bf16_t* __restrict__ out, stat_t* __restrict__ stats_out) {
+                                                           bf16_t* __restrict__ out, stat_t* __restrict__ stats_out,
+                                                           int tiles, int ncb, int nb) {
     __shared__ uint4 halo[324];
     __shared__ uint4 wl[2 * 5 * 64];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) unsigned char otile[4 * 32 * 144];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, cb = blockIdx.y;
-    const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
-    {   // halo gather: both pixels of a thread (324 = 256 + 68) have their loads in flight before either is packed
-        float v[2][8];
+    // PERSISTENT (round 5): workgroup g walks units g, g + gridDim.x, ... of (sample, channel block, tile), tile fastest; the gather of the
+    // NEXT unit's halo (CIN scalar fp32 loads per pixel, NCHW) is in flight under the current unit's MFMAs, epilogue and stores, and the
+    // weight fragments are copied when the channel block changes (once per workgroup at C0 = 64)
+    const int total = tiles * ncb * nb;
+    auto gather = [&](int u, float (&v)[2][8]) {        // both pixels of a thread (324 = 256 + 68) have their loads in flight together
+        const int tile = u % tiles, b = u / (tiles * ncb);
+        const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int hp = tid + u * 256;
+        for (int uu = 0; uu < 2; ++uu) {
+            const int hp = tid + uu * 256;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+            for (int k = 0; k < 8; ++k) v[uu][k] = 0.f;
             if (hp < 324) {
                 const int hr = hp / 18, hc = hp - hr * 18;
                 const int yy = y0 + hr - 1, xx = x0 + hc - 1;
@@ -102,88 +106,100 @@ __global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const float* __restri
 #pragma unroll
                     for (int ci = 0; ci < CIN; ++ci) {
                         const float* src = ci < 3 ? cond : xt;
-                        v[u][ci] = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
+                        v[uu][ci] = src[(((long long)b * 3 + (ci % 3)) * H + ys) * W + xs];
                     }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (tid + u * 256 < 324) halo[tid + u * 256] = pack8_bf16(v[u]);
-    }
-    // this block's weight fragments (10 KB, shared by the four waves) go to LDS once; 40 VGPRs of resident fragments
-    // would cost half the occupancy
-    for (int i = tid; i < 2 * 5 * 64; i += 256)
-        wl[i] = *reinterpret_cast<const uint4*>(wfrag + ((long long)cb * 2 * 5 * 64 + i) * 8);
-    __syncthreads();
-    int hp0[2];
-#pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-        const int slot = tp * 32 + (lane & 31);
-        hp0[tp] = (wv * 4 + (slot >> 4)) * 18 + (slot & 15);
-    }
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+    };
+    float v[2][8];
+    if ((int)blockIdx.x < total) gather(blockIdx.x, v);
+    int cb_cur = -1;
 #pragma unroll 1
-    for (int j = 0; j < 5; ++j) {                       // not unrolled: hipcc would hoist all 20 fragment reads (80 VGPRs)
-        const int t0 = 2 * j, t1 = (2 * j + 1 > 8) ? 8 : 2 * j + 1;
-        const int sh = hh ? (t1 / 3) * 18 + (t1 % 3) : (t0 / 3) * 18 + (t0 % 3);
-        bf16x8_t af[2], bfr[2];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        const int tile = u % tiles, cb = (u / tiles) % ncb, b = u / (tiles * ncb);
+        const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+        __syncthreads();                                 // the previous unit is done with the halo (and with `red`)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const bf16x8_t*>(&wl[(tm * 5 + j) * 64 + lane]);
+        for (int uu = 0; uu < 2; ++uu)
+            if (tid + uu * 256 < 324) halo[tid + uu * 256] = pack8_bf16(v[uu]);
+        // this block's weight fragments (10 KB, shared by the four waves) go to LDS; 40 VGPRs of resident fragments would cost half the occupancy
+        if (cb != cb_cur) {
+            for (int i = tid; i < 2 * 5 * 64; i += 256)
+                wl[i] = *reinterpret_cast<const uint4*>(wfrag + ((long long)cb * 2 * 5 * 64 + i) * 8);
+            cb_cur = cb;
+        }
+        if (u + (int)gridDim.x < total) gather(u + gridDim.x, v);
+        __syncthreads();
+        int hp0[2];
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-            bfr[tp] = *reinterpret_cast<const bf16x8_t*>(&halo[hp0[tp] + sh]);
-            if (j == 4 && hh) bfr[tp] = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0u, 0u, 0u));   // bias slot: (1, 1, 0, ...) x (hi, lo)
+            const int slot = tp * 32 + (lane & 31);
+            hp0[tp] = (wv * 4 + (slot >> 4)) * 18 + (slot & 15);
         }
+        f32x16_t acc[2][2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
-                acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
-    }
-    float s1 = 0.f, s2 = 0.f;
-    unsigned char* ot = otile + wv * (32 * 144);
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {                       // one 32-pixel MFMA tile (two tile rows) per pass
-        {
-            const int slot = lane & 31;
-            const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
-            const bool inb = y < Hc && x < Wc;
+                for (int e = 0; e < 16; ++e) acc[tm][tp][e] = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < 5; ++j) {                       // not unrolled: hipcc would hoist all 20 fragment reads (80 VGPRs)
+            const int t0 = 2 * j, t1 = (2 * j + 1 > 8) ? 8 : 2 * j + 1;
+            const int sh = hh ? (t1 / 3) * 18 + (t1 % 3) : (t0 / 3) * 18 + (t0 % 3);
+            bf16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const bf16x8_t*>(&wl[(tm * 5 + j) * 64 + lane]);
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                bfr[tp] = *reinterpret_cast<const bf16x8_t*>(&halo[hp0[tp] + sh]);
+                if (j == 4 && hh) bfr[tp] = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0u, 0u, 0u));   // bias slot: (1, 1, 0, ...) x (hi, lo)
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = tm * 32 + 8 * g + 4 * hh;
-                    float v[4] = {acc[tm][tp][4 * g + 0], acc[tm][tp][4 * g + 1], acc[tm][tp][4 * g + 2], acc[tm][tp][4 * g + 3]};
+                for (int tp = 0; tp < 2; ++tp)
+                    acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
+        }
+        float s1 = 0.f, s2 = 0.f;
+        unsigned char* ot = otile + wv * (32 * 144);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (ACT == 2) v[i] = fmaxf(0.2f * v[i], v[i]);
-                        if (inb) { s1 += v[i]; s2 += v[i] * v[i]; }
+        for (int tp = 0; tp < 2; ++tp) {                       // one 32-pixel MFMA tile (two tile rows) per pass
+            {
+                const int slot = lane & 31;
+                const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
+                const bool inb = y < Hc && x < Wc;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = tm * 32 + 8 * g + 4 * hh;
+                        float vv[4] = {acc[tm][tp][4 * g + 0], acc[tm][tp][4 * g + 1], acc[tm][tp][4 * g + 2], acc[tm][tp][4 * g + 3]};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (ACT == 2) vv[i] = fmaxf(0.2f * vv[i], vv[i]);
+                            if (inb) { s1 += vv[i]; s2 += vv[i] * vv[i]; }
+                        }
+                        *reinterpret_cast<uint2*>(ot + slot * 144 + ch * 2) = make_uint2(pack2_bf16(vv[0], vv[1]), pack2_bf16(vv[2], vv[3]));
                     }
-                    *reinterpret_cast<uint2*>(ot + slot * 144 + ch * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
-                }
-        }
-        // the tile is private to the wave: program order + the compiler's lgkmcnt waits make its writes visible to it
+            }
+            // the tile is private to the wave: program order + the compiler's lgkmcnt waits make its writes visible to it
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = i * 64 + lane, slot = idx >> 3, c16 = idx & 7;
-            const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
-            if (y < Hc && x < Wc)
-                *reinterpret_cast<uint4*>(out + (((long long)b * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C0 + cb * 64 + c16 * 8) =
-                    *reinterpret_cast<const uint4*>(ot + slot * 144 + c16 * 16);
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 64 + lane, slot = idx >> 3, c16 = idx & 7;
+                const int y = y0 + wv * 4 + tp * 2 + (slot >> 4), x = x0 + (slot & 15);
+                if (y < Hc && x < Wc)
+                    *reinterpret_cast<uint4*>(out + (((long long)b * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C0 + cb * 64 + c16 * 8) =
+                        *reinterpret_cast<const uint4*>(ot + slot * 144 + c16 * 16);
+            }
         }
-    }
-    if (stats_out) {
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-        if (lane == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
-        __syncthreads();
-        if (tid == 0) stat_add(stats_out, b, red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
+        if (stats_out) {                                   // per unit, as the one-shot kernel did: the same fp32 partials -> the same fixed-point sums
+            for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+            if (lane == 0) { red[wv * 2] = s1; red[wv * 2 + 1] = s2; }
+            __syncthreads();
+            if (tid == 0) stat_add(stats_out, b, red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
+        }
     }
 }
 
