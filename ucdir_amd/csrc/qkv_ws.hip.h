@@ -11,8 +11,8 @@
 //   * it walks a contiguous range of 128-pixel tiles (tiles never cross a sample); the pixels' channels arrive in chunks of 128
 //     channels ([128 px][128 ch] bf16 = 32 KB, ring of three) by LDS-DMA, chunks c + 1 and c + 2 (of this or the next tile) in
 //     flight under the MFMAs of chunk c: ONE barrier per chunk, counted vmcnt;
-//   * LDS rows of 256 bytes, 16-byte chunk XOR f(pixel), f = (px & 15) ^ 8 [px & 16], on the DMA's source side: the 16 lanes of a
-//     ds_read_b128 group read 16 different slots in both lane -> pixel mappings below;
+//   * LDS rows of 256 bytes, 16-byte chunk XOR f(pixel), f = px & 15, on the DMA's source side: the 16 lanes of a
+//     ds_read_b128 group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) read 16 different slots in both lane -> pixel mappings below;
 //   * q / k tiles: weights are the A operand, rows permuted at pack time so that a lane ends up with 16 consecutive features of
 //     one pixel (32-byte stores);  v' tiles: the SAME registers are the B operand and the pixels the A operand (the fragment
 //     layouts of v_mfma_f32_32x32x16 are symmetric), pixel rows permuted in the LDS read address instead: a lane ends up with 16
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void qkv_ws_kernel(const QkvP p) {
     // B / A fragment of pixel tile tp, k step j of a chunk: pixel 32 tp + px, logical chunk 2 j + hh
     //   q / k: px = l31;  v': px = pi(l31) = 16 ((l31 >> 2) & 1) + 4 (l31 >> 3) + (l31 & 3)  (a lane's 16 accumulators = 16 consecutive pixels)
     const int pxl = is_v ? (16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3)) : l31;
-    auto swz = [](int px) { return (px & 15) ^ (((px >> 4) & 1) << 3); };
+    // (round 5: was (px & 15) ^ 8 [px & 16], built for lane groups {0-7, 16-23}; ds_read_b128 is serviced in {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
+    // (conv_halo.hip.h), where that XOR makes the two tile rows of a group collide - SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles, 51.0 -> 48.8 us)
+    auto swz = [](int px) { return px & 15; };
     // LDS byte address of (pixel tile 0, k step 0) in buffer 0; k step j: ^ 32 j (chunk 2 j + hh = (2 j) ^ hh), pixel tile tp: + 8192 tp
     const unsigned fr0 = pxl * 256 + ((hh ^ swz(pxl)) << 4);
 
