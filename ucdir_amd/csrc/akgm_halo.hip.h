@@ -70,6 +70,15 @@ __device__ __forceinline__ void akgm_tc_piece(const AkgmHP& p, long long rel, un
     *reinterpret_cast<float4*>(dst) = make_float4(tb.x * inv - mean * tg.x, tb.y * inv - mean * tg.y, tb.z * inv - mean * tg.z, tb.w * inv - mean * tg.w);
 }
 
+// the slice Tc[b][cls][8 fbase .. + 128) of a one-shot AKGM workgroup, formed where the LDS-DMA from akgm_tc_kernel's table was issued: waves 0 - 4,
+// lane -> (class 2 w + lane / 32, 16 bytes), the DMA's LDS addresses.  The caller makes the writes visible (lgkmcnt(0) in front of its next barrier).
+__device__ __forceinline__ void akgm_tc_slice(const AkgmHP& p, int fbase, float* dst, int wave, int lane, float inv, float mean) {
+    if (wave < 5) {
+        const int cl = 2 * wave + (lane >> 5);
+        if (cl < 9) akgm_tc_piece(p, (long long)cl * 8 * p.C + 8 * fbase + (lane & 31) * 4, reinterpret_cast<unsigned char*>(dst) + wave * 1024 + lane * 16, inv, mean);
+    }
+}
+
 // ATT_LDS (16 / 32 channels per group: one halo chunk per workgroup, the second halo buffer is free): the per-pixel
 // modulation weights G*attw live in that buffer instead of 16 VGPRs, and the accumulators start at the fold constants
 // (as in akgm_pre.hip.h) so the epilogue needs 8 instead of 16 FMAs per output.  With 64 per group both halo buffers
@@ -110,7 +119,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift   (cg >= 16)
     const int spc = (cg == 8) ? 2 : ((cg == 16) ? 3 : 5);   // A stages (64 k) per 32-channel period
 
-    const float rstd = p.ms[2 * b + 1];
+    float rstd, mean_b = 0.f;
+    if (p.own_tc) stat_mean_rstd_wave(p.stats, b, p.inv_count, lane, mean_b, rstd);   // (no akgm_tc_kernel launch in front: AkgmHP::own_tc)
+    else rstd = p.ms[2 * b + 1];
+    const float inv_b = 1.0f / rstd;
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
     {
@@ -194,8 +206,13 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_kernel(const AkgmHP p
     // while nothing of unit u reads its own any more); the second one sits behind the modulation weights in the free halo
     // buffer.  Without ATT_LDS the slice is read in the epilogue: one buffer, refilled after the next unit's first barrier.
     float* tcs1 = ATT_LDS ? attl + 256 * 8 : tcs;
+    // (own_tc: the slice is formed from the sample-independent tables by plain loads - issued and waited for IN FRONT of the weight stage's DMA
+    // that follows every call, so that only an L2 round trip of two 16-byte loads is exposed - and written to the DMA's LDS addresses)
     auto issue_Tc = [&](int fbase, float* dst) {
-        if (wave < 5) {
+        if (p.own_tc) {
+            akgm_tc_slice(p, fbase, dst, wave, lane, inv_b, mean_b);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (wave < 5) {
             const int cl = 2 * wave + (lane >> 5);
             if (cl < 9)
                 __builtin_amdgcn_global_load_lds(
@@ -445,7 +462,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_stage_kernel(const Ak
     const int tshift = (cg == 16) ? 0 : 1;                  // k16 step -> tap: tap = k16 >> tshift   (cg >= 16)
     const int spc = (cg == 8) ? 2 : ((cg == 16) ? 3 : 5);   // A stages (64 k) per 32-channel period
 
-    const float rstd = p.ms[2 * b + 1];
+    float rstd, mean_b = 0.f;
+    if (p.own_tc) stat_mean_rstd_wave(p.stats, b, p.inv_count, lane, mean_b, rstd);   // (no akgm_tc_kernel launch in front: AkgmHP::own_tc)
+    else rstd = p.ms[2 * b + 1];
+    const float inv_b = 1.0f / rstd;
 
     // ---- halo: stage chunk(s) once -----------------------------------------------------------------
     {
@@ -524,7 +544,10 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_halo_stage_kernel(const Ak
         __syncthreads();                        // previous unit's phase 2 done with stage / tcs
         // fold table slice of this unit, Tc[b][cls][8*fbase .. +128), DMA'd into LDS next to the first A stage:
         // instruction w (waves 0-4) carries classes 2w and 2w+1 (32 lanes x 16 B each)
-        if (wave < 5) {
+        if (p.own_tc) {
+            akgm_tc_slice(p, fbase, tcs, wave, lane, inv_b, mean_b);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (visible behind the first K step's barrier)
+        } else if (wave < 5) {
             const int cl = 2 * wave + (lane >> 5);
             if (cl < 9)
                 __builtin_amdgcn_global_load_lds(

@@ -106,10 +106,16 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
         }
     };
     issue_A(unit0, 0, L::NA * (L::A_UNIT / 1024));
-    issue_Tc(unit0 * 16, tcs);
-    if (CG == 8) issue_Tc(unit0 * 16 + 16, tcs + 9 * 128);
+    float rstd, mean_b = 0.f;
+    if (p.own_tc) stat_mean_rstd_wave(p.stats, b, p.inv_count, lane, mean_b, rstd);   // (no akgm_tc_kernel launch in front: AkgmHP::own_tc)
+    else rstd = p.ms[2 * b + 1];
+    const float inv_b = 1.0f / rstd;
+    auto tc_slice = [&](int fbase, float* dst) {
+        if (p.own_tc) akgm_tc_slice(p, fbase, dst, wave, lane, inv_b, mean_b); else issue_Tc(fbase, dst);
+    };
+    tc_slice(unit0 * 16, tcs);
+    if (CG == 8) tc_slice(unit0 * 16 + 16, tcs + 9 * 128);
 
-    const float rstd = p.ms[2 * b + 1];
     // ---- per-lane pixel constants (K loop / phase 1) ---------------------------------------------------
     int hp0[2], cls[2];                                                // cls: border class, or -1 for a pixel outside the image / tile
 #pragma unroll
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(HC_THREADS, 4) void akgm_pre_kernel(const AkgmHP p)
         if (CG == 16 && u == 0) {            // unit 1's weights / fold table replace unit 0's: every wave is done reading them
             __syncthreads();
             issue_A(unit0 + 1, 0, 36);
-            issue_Tc(fbase + 16, tcs);
+            tc_slice(fbase + 16, tcs);
         }
         // ---- modulation sum in registers: vq[tm][q][tp] = feature 8 wm + 4 tm + 2 hh + q of pixel tp (pack_akgm_pre) --
         float vq[2][2][2];

@@ -855,7 +855,8 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
     if (ws64) { p.A = w.Aws64; p.th = npt64; p.tiles_x = tps64; p.tiles_y = 1; }
     // the persistent kernels form their fold constants themselves (27 launches of ~5 us less per B = 16 forward; UCDIR_NO_OWNTC=1: akgm_tc_kernel for all)
     static const bool use_owntc = !getenv("UCDIR_NO_OWNTC");
-    p.own_tc = use_owntc && (ws64 || ws32 || ws || ws16) && w.Tbb != nullptr;
+    // (round 5, late: the one-shot kernels of the B = 1 path as well - their Tc slices are formed where the LDS-DMA from akgm_tc_kernel's table was issued)
+    p.own_tc = use_owntc && w.Tbb != nullptr;
     p.Tbb = w.Tbb; p.Tgt = w.Tg;
     if (!p.own_tc)
         hipLaunchKernelGGL(akgm_tc_kernel, dim3(9 * ((8 * w.C + 1023) / 1024), y.B), dim3(256), 0, st, h1.stats, inv_cnt, w.bias, w.Tb, w.Tg, 8 * w.C, tcbuf, msbuf);
