@@ -18,6 +18,7 @@
 // with 9 border classes (which taps fall on the zero border), so the kernel reads raw x.
 #pragma once
 #include "common.h"
+#include "asmops.hip.h"
 
 #define CG_TP 128
 #define CG_BK 64
@@ -59,6 +60,13 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     constexpr int KBUF = cgemm_kbuf_bytes<TM>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef UCDIR_TIMING
+    int cg_n = 0;
+#define CG_STAMP() do { if (p.dbg && blockIdx.x == gridDim.x / 2 && tid == 0 && cg_n < 60) p.dbg[cg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CG_STAMP() do {} while (0)
+#endif
+    CG_STAMP();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: no waterfall loops around global_load_lds
     const int wm = wave >> 1, wp = wave & 1;
 
@@ -194,45 +202,56 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             }
         };
 
-        // fragment read offsets (bytes within a tile buffer), fixed per lane
-        int a_off[TMT], a_sw[TMT], b_off[2], b_sw[2];
+        // fragment read addresses (LDS bytes, buffer 0, k16 step 0), fixed per lane: row * 128 + ((chunk ^ swizzle) << 4) with chunk = 2 kk + lane / 32 =
+        // (2 kk) ^ (lane / 32): step kk is the same address ^ (kk << 5), buffer 1 is + TM * 128 (A) / + CG_TP * 128 (B)
+        unsigned a_ad[TMT], b_ad[2];
 #pragma unroll
         for (int tm = 0; tm < TMT; ++tm) {
-            int row = wm * (TM / 2) + tm * 32 + (lane & 31);
-            a_off[tm] = row * 128; a_sw[tm] = (row >> 1) & 7;
+            const int row = wm * (TM / 2) + tm * 32 + (lane & 31);
+            a_ad[tm] = (unsigned)(row * 128 + ((((lane >> 5) ^ (row >> 1)) & 7) << 4));
         }
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-            int row = wp * 64 + tp * 32 + (lane & 31);
-            b_off[tp] = row * 128; b_sw[tp] = (row >> 1) & 7;
+            const int row = wp * 64 + tp * 32 + (lane & 31);
+            b_ad[tp] = (unsigned)(2 * TM * 128 + row * 128 + ((((lane >> 5) ^ (row >> 1)) & 7) << 4));
         }
 
+        CG_STAMP();
         issue(0, 0);
         for (int ks = 0; ks < p.nk; ++ks) {
             const int buf = ks & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            CG_STAMP();
             if (ks + 1 < p.nk) issue(ks + 1, buf ^ 1);
-            const unsigned char* Ab = smem + buf * (TM * 128);
-            const unsigned char* Bb = smem + 2 * TM * 128 + buf * (CG_TP * 128);
+            // the four k16 steps of the stage, software-pipelined by hand (round 5): inline-asm fragment reads with counted lgkmcnt, the reads of
+            // step kk + 1 in flight under the MFMAs of step kk.  hipcc's own schedule was read -> lgkmcnt(0) -> MFMAs per step: an LDS round trip in
+            // front of every four MFMAs (the K step of a stride-2 conv ran at ~1.3 k cycles for 512 cycles of matrix work)
+            const unsigned ao = (unsigned)(buf * (TM * 128)), bo = (unsigned)(buf * (CG_TP * 128));
+            bf16x8_t af[2][TMT], bfr[2][2];
+            auto rd = [&](auto kkc) {
+                constexpr int kk = decltype(kkc)::value;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int kch = kk * 2 + (lane >> 5);
-                bf16x8_t af[TMT], bfr[2];
+                for (int tm = 0; tm < TMT; ++tm) lds_read16_asm<0>(af[kk & 1][tm], (a_ad[tm] + ao) ^ (unsigned)(kk << 5));
 #pragma unroll
-                for (int tm = 0; tm < TMT; ++tm)
-                    af[tm] = *reinterpret_cast<const bf16x8_t*>(Ab + a_off[tm] + ((kch ^ a_sw[tm]) << 4));
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-                    bfr[tp] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[tp] + ((kch ^ b_sw[tp]) << 4));
+                for (int tp = 0; tp < 2; ++tp) lds_read16_asm<0>(bfr[kk & 1][tp], (b_ad[tp] + bo) ^ (unsigned)(kk << 5));
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, 0>{});
+            static_for<0, 4>([&](auto kkc) {
+                constexpr int kk = decltype(kkc)::value;
+                if constexpr (kk + 1 < 4) rd(std::integral_constant<int, kk + 1>{});
+                lgkm_wait_asm<(kk + 1 < 4) ? TMT + 2 : 0>();
 #pragma unroll
                 for (int tm = 0; tm < TMT; ++tm)
 #pragma unroll
                     for (int tp = 0; tp < 2; ++tp)
-                        acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tp], acc[tm][tp], 0, 0, 0);
-            }
+                        acc[tm][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][tm], bfr[kk & 1][tp], acc[tm][tp], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
         }
 
+        CG_STAMP();
         // ---- epilogue phase 1: accumulator layout -> fp32 staging tile [pixel][feature] -------
         if (EPI == EPI_STD) {
             __syncthreads();                       // staging aliases the K buffers
@@ -300,6 +319,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     }
     __syncthreads();
 
+    CG_STAMP();
     // ---- epilogue phase 2: coalesced layout, 8 features per thread-item ---------------------------
     const float rstd_s = scal[1];
     const float mr_s = scal[0] * scal[1];
@@ -312,6 +332,24 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
     }
     const int nf8 = NF >> 3;
     float s1 = 0.f, s2 = 0.f;
+    // A thread's eight features are the same in every item when nf8 divides the workgroup size (it = tid + 256 k): its bias and the fold-table
+    // entries of the interior class are loaded ONCE in front of the loop (round 5: six 16-byte L2 round trips per item, serialised by the
+    // not-unrolled loop, were a quarter of a small launch - stamps in profiles/EXPERIMENTS.md); border pixels of a 3x3 conv reload their class
+    const bool hoist = EPI == EPI_STD && (CG_THREADS % nf8) == 0;
+    float4 hb0 = make_float4(0.f, 0.f, 0.f, 0.f), hb1 = hb0, ht0 = hb0, ht1 = hb0, hg0 = hb0, hg1 = hb0;
+    const int hcls = (p.ntaps == 9) ? 4 : 0;
+    if (hoist) {
+        const int fh = fbase + (tid % nf8) * 8;
+        if (fh < p.nfeat) {
+            if (p.bias) { hb0 = *reinterpret_cast<const float4*>(p.bias + fh); hb1 = *reinterpret_cast<const float4*>(p.bias + fh + 4); }
+            if (p.fold) {
+                const float* tb = p.Tb + (long long)hcls * p.tab_ld + fh;
+                const float* tg = p.Tg + (long long)hcls * p.tab_ld + fh;
+                ht0 = *reinterpret_cast<const float4*>(tb); ht1 = *reinterpret_cast<const float4*>(tb + 4);
+                hg0 = *reinterpret_cast<const float4*>(tg); hg1 = *reinterpret_cast<const float4*>(tg + 4);
+            }
+        }
+    }
     for (int it = tid; it < CG_TP * nf8; it += CG_THREADS) {
         const int px = it / nf8;
         const int f8 = (it - px * nf8) * 8;
@@ -341,16 +379,24 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
         if (EPI == EPI_STD) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] *= alpha;
+            // (16-byte table loads: f is a multiple of 8 and the tables are allocation-aligned; eight scalar loads per array and item - 24 dependent
+            // L2 round trips per item, eight items per thread - were most of a small launch's epilogue)
             if (p.bias) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += p.bias[f + i];
+                float4 b0 = hb0, b1 = hb1;
+                if (!hoist) { b0 = *reinterpret_cast<const float4*>(p.bias + f); b1 = *reinterpret_cast<const float4*>(p.bias + f + 4); }
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
             }
             if (p.fold) {
                 const int ncls_row = (p.ntaps == 9) ? cls : 0;
-                const float* tb = p.Tb + (long long)ncls_row * p.tab_ld + f;
-                const float* tg = p.Tg + (long long)ncls_row * p.tab_ld + f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += tb[i] - mr_s * tg[i];
+                float4 t0 = ht0, t1 = ht1, g0 = hg0, g1 = hg1;
+                if (!hoist || ncls_row != hcls) {
+                    const float* tb = p.Tb + (long long)ncls_row * p.tab_ld + f;
+                    const float* tg = p.Tg + (long long)ncls_row * p.tab_ld + f;
+                    t0 = *reinterpret_cast<const float4*>(tb); t1 = *reinterpret_cast<const float4*>(tb + 4);
+                    g0 = *reinterpret_cast<const float4*>(tg); g1 = *reinterpret_cast<const float4*>(tg + 4);
+                }
+                v[0] += t0.x - mr_s * g0.x; v[1] += t0.y - mr_s * g0.y; v[2] += t0.z - mr_s * g0.z; v[3] += t0.w - mr_s * g0.w;
+                v[4] += t1.x - mr_s * g1.x; v[5] += t1.y - mr_s * g1.y; v[6] += t1.z - mr_s * g1.z; v[7] += t1.w - mr_s * g1.w;
             }
         }
         if (p.act) {
@@ -389,6 +435,10 @@ __global__ __launch_bounds__(CG_THREADS, 2) void cgemm_kernel(const GemmP p) {
             *reinterpret_cast<uint4*>(op) = p.out_f16 ? pack8_f16(v) : pack8_bf16(v);
         }
     }
+    CG_STAMP();
+#ifdef UCDIR_TIMING
+    if (p.dbg && blockIdx.x == gridDim.x / 2 && tid == 0) p.dbg[63] = cg_n;
+#endif
     if (p.stats_out) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {

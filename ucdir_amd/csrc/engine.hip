@@ -273,7 +273,18 @@ static void launch_cgemm(const GemmP& p, int TM, int epi, hipStream_t st) {
     g_prof.entries.push_back(e);
 }
 
-static void launch_cgemm_impl(const GemmP& p, int TM, int epi, hipStream_t st) {
+static void launch_cgemm_impl(const GemmP& p0, int TM, int epi, hipStream_t st) {
+    GemmP p = p0;
+#ifdef UCDIR_TIMING
+    static unsigned long long* cgdbg = nullptr;
+    if (!cgdbg) HIPC(hipMalloc((void**)&cgdbg, 64 * 8));
+    HIPC(hipMemsetAsync(cgdbg, 0, 64 * 8, st));
+    p.dbg = cgdbg;
+    struct Pr { unsigned long long* d; hipStream_t s; int mode, TM, nk; ~Pr() {
+        unsigned long long h[64]; (void)hipStreamSynchronize(s); (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        const int n = (int)h[63]; fprintf(stderr, "CGEMM TIMING mode=%d TM=%d nk=%d n=%d:", mode, TM, nk, n);
+        for (int i = 1; i < n && i < 60; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]); fprintf(stderr, "\n"); } } pr{cgdbg, st, p.cols_mode, TM, p.nk};
+#endif
     const int nblk = p.nbatch * p.tiles * p.rowtiles;
     const size_t lds = cgemm_lds_bytes(TM, epi, p.groups_per_wg);
     dim3 grid(nblk);
