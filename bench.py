@@ -46,6 +46,28 @@ def sid_opt():
                       "diffusion": dict(image_size=128, channels=3, conditional=True)}}
 
 
+def host_cpu_info():
+    """CPU model and core counts of the box the baseline ran on (`lscpu`): `cores` in the record is the thread
+    count the oracle was given, these say what the host has."""
+    info = {"cpu_model": None, "physical_cores": None, "logical_cpus": os.cpu_count(), "sockets": None}
+    try:
+        import subprocess
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["cpu_model"] = kv.get("Model name")
+        sockets = int(kv.get("Socket(s)", "0") or 0)
+        cps = int(kv.get("Core(s) per socket", "0") or 0)
+        info["sockets"] = sockets or None
+        info["physical_cores"] = sockets * cps if sockets and cps else None
+    except Exception:
+        pass
+    return info
+
+
 def cpu_baseline(T, size):
     """CPU restatement (the oracle) on the host cores: bounded sample = predictor + 3 of the T forwards (min), B=1."""
     from oracle import ucdir_oracle as O
@@ -69,7 +91,7 @@ def cpu_baseline(T, size):
             O.dy3h_forward(sd, x6, lvl, g)
             times.append(time.time() - t0)
         tf = min(times)
-    return {"value": 1.0 / (T * tf + tp), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / (T * tf + tp), "unit": "images/s", "cores": cores, "kind": "port", **host_cpu_info(),
             "sample": f"B=1 {size}x{size}: predictor + {n} of {T} UNet forwards timed, fastest {tf:.3f} s/forward "
                       f"(all: {', '.join('%.3f' % t for t in times)}), extrapolated to {T} steps; fp32 torch CPU "
                       f"restatement (oracle/)"}

@@ -41,7 +41,7 @@ extern "C" {
 /* 4: ucdir_gather_windows and ucdir_matrix_rate joined the interface (round 4); a binding built against version 3 must not load this library
  * silently (round-4 verdict).  Round 5 added no symbol: new kernels are dispatch changes behind the same entry points (A/B switches: the
  * environment variables of DESIGN.md and ucdir_debug_flag names "flash2", "persist_grid", ...). */
-#define UCDIR_ABI_VERSION 4
+#define UCDIR_ABI_VERSION 5
 #define UCDIR_MAX_MULTS 8
 
 typedef struct ucdir_ctx ucdir_ctx;
@@ -121,6 +121,15 @@ int32_t ucdir_sampler_step_rng(float* x_t, const float* eps, int64_t n,
                                float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
                                uint64_t seed, uint32_t step, void* stream);
 int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, void* stream);
+/* Per-sample streams (ABI 5; sr.py -p val restores same-sized images as one batch, reference sr.py:518-561 runs them one by one through
+ * data/__init__.py:47 batch_size 1): the buffer is n / per samples of `per` fp32 elements (per a multiple of 4); sample b draws
+ * Philox4x32-10(key = seeds_dev[b], counter = (local element / 4, step)) - exactly what ucdir_sampler_step_rng / ucdir_fill_normal
+ * draw for a buffer that holds this sample alone with seed = seeds_dev[b].  An image's noise therefore does not depend on the batch it
+ * is grouped into.  seeds_dev: n / per uint64 values ON THE DEVICE of the buffer. */
+int32_t ucdir_sampler_step_rng_batched(float* x_t, const float* eps, int64_t n, int64_t per,
+                                       float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
+                                       const uint64_t* seeds_dev, uint32_t step, void* stream);
+int32_t ucdir_fill_normal_batched(float* x, int64_t n, int64_t per, const uint64_t* seeds_dev, uint32_t step, void* stream);
 /* Window batch of the inter-step patch split (utils/util.py:113-137: F.pad(..., mode='reflect') then one slice per window) in ONE launch,
  * straight from the un-padded canvas: out[(w * B + b)][c][y][x] = x[b][c][refl(h0_w + y - pad)][refl(w0_w + x - pad)], x (B, C, H, W) fp32,
  * out (nwin * B, C, skip, skip) fp32, win_dev = nwin pairs (h0, w0) of int32 ON THE DEVICE in padded coordinates (the window list of

@@ -19,6 +19,7 @@ import argparse
 import logging
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -47,6 +48,9 @@ def main(argv=None):
     parser.add_argument("--synthetic-weights", action="store_true",
                         help="fill netG with the deterministic test weights (no checkpoint ships with the reference)")
     parser.add_argument("--max-images", type=int, default=-1)
+    parser.add_argument("--batch", type=int, default=16,
+                        help="restore up to this many same-sized val images per DDPM.test call (1: the reference's one-by-one loop)")
+    parser.add_argument("--seed", type=int, default=None, help="base of the per-image noise seeds (default: one random draw per run)")
     args = parser.parse_args(argv)
     if args.phase != "val":
         raise SystemExit("only -p val is implemented (sampling path); training is out of scope of this build")
@@ -85,7 +89,47 @@ def main(argv=None):
     idxs = list(range(len(val_set)))
     if args.max_images > 0:
         idxs = idxs[:args.max_images * world]
-    thr = diffusion.netG.denoise_fn.patch_threshold
+    dn = diffusion.netG.denoise_fn
+    thr = dn.patch_threshold
+    # Per-image noise streams: image i draws Philox(seed_base + 1000003 i) with counters local to the image, whatever batch or rank it is
+    # restored in.  --seed fixes the base; without it one draw from torch's CPU generator per run (torch.manual_seed makes it reproducible).
+    diffusion.image_seed_base = args.seed if args.seed is not None else int(torch.randint(0, 2 ** 31, (1,)).item())
+    t_restore, n_restored = 0.0, 0
+
+    def restore(group):
+        """One DDPM.test call for a group of images of identical (H, W): a batch is B independent restorations (model/diffusion.py:185-211
+        is written for a batch; the reference's val loader feeds it batch_size 1, data/__init__.py:47)."""
+        nonlocal tot_psnr, tot_ssim, n, t_restore, n_restored
+        items = [g[1] for g in group]
+        data = {k: torch.stack([it[k] for it in items]) for k in ("HR", "SR", "LR") if k in items[0]}
+        data["Index"] = [g[0] for g in group]                    # DDPM.test derives every image's noise stream from its index
+        small = (items[0]["SR"].shape[-2] + 128) * (items[0]["SR"].shape[-1] + 128) <= thr
+        dn.set_graph(len(group) == 1 and small)                  # batch-1 remainders: HIP-graph replay of the forward (latency path)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            diffusion.feed_data(data)
+            diffusion.test(continous=True)
+        torch.cuda.synchronize()
+        t_restore += time.perf_counter() - t0
+        n_restored += len(group)
+        if group[0][2] and rank != 0:
+            return                                                # sharded image: every rank holds the same result; rank 0 reports it
+        name = opt["name"]
+        for j, (i, _, _) in enumerate(group):
+            fname = os.path.splitext(os.path.basename(val_set.sr_path[i]))[0]
+            vis = diffusion.visuals_u8(j)
+            hr_img, lr_img, fake_img, sr_img = vis["HR"], vis["LR"], vis["INF"], vis["SR"]
+            Metrics.save_jpg(sr_img, "{}/{}_{}_sr.png".format(result_path, fname, name))
+            Metrics.save_jpg(hr_img, "{}/{}_{}_hr.png".format(result_path, fname, name))
+            Metrics.save_jpg(lr_img, "{}/{}_{}_lr.png".format(result_path, fname, name))
+            Metrics.save_jpg(fake_img, "{}/{}_{}_inf.png".format(result_path, fname, name))
+            tot_psnr += Metrics.calculate_psnr(sr_img, hr_img)
+            tot_ssim += Metrics.calculate_ssim(sr_img, hr_img)
+            n += 1
+            logger.info("val index %d" % i)
+
+    pending = {}                                                  # (H, W) -> images of this rank waiting for a full batch (first-seen order)
     nsmall = 0
     for i in idxs:
         item = val_set[i]
@@ -96,25 +140,19 @@ def main(argv=None):
             nsmall += 1
             if not mine:
                 continue
-        fname = os.path.splitext(os.path.basename(val_set.sr_path[i]))[0]
-        data = {k: (v.unsqueeze(0) if torch.is_tensor(v) else v) for k, v in item.items()}
-        data["Index"] = i                                         # DDPM.test offsets the rank-identical noise seed by the image index
-        with torch.no_grad():
-            diffusion.feed_data(data)
-            diffusion.test(continous=True)
-        if shared and rank != 0:
-            continue                                              # every rank holds the same result; rank 0 reports it
-        vis = diffusion.visuals_u8()
-        hr_img, lr_img, fake_img, sr_img = vis["HR"], vis["LR"], vis["INF"], vis["SR"]
-        name = opt["name"]
-        Metrics.save_jpg(sr_img, "{}/{}_{}_sr.png".format(result_path, fname, name))
-        Metrics.save_jpg(hr_img, "{}/{}_{}_hr.png".format(result_path, fname, name))
-        Metrics.save_jpg(lr_img, "{}/{}_{}_lr.png".format(result_path, fname, name))
-        Metrics.save_jpg(fake_img, "{}/{}_{}_inf.png".format(result_path, fname, name))
-        tot_psnr += Metrics.calculate_psnr(sr_img, hr_img)
-        tot_ssim += Metrics.calculate_ssim(sr_img, hr_img)
-        n += 1
-        logger.info("val index %d" % i)
+        if shared or args.batch <= 1 or (h + 128) * (w + 128) > thr:
+            restore([(i, item, shared)])                          # patch-split images (1024^2 windows as engine batches) go one at a time
+            continue
+        grp = pending.setdefault((h, w), [])
+        grp.append((i, item, False))
+        if len(grp) >= args.batch:
+            restore(pending.pop((h, w)))
+    for key in list(pending):
+        restore(pending.pop(key))
+    dn.set_graph(False)
+    if n_restored:
+        logger.info("restored %d images in %.2f s on this rank (%.2f img/s, batches of up to %d)" % (n_restored, t_restore, n_restored / t_restore, args.batch))
+    main.last_throughput = (n_restored, t_restore)
     acc = torch.tensor([tot_psnr, tot_ssim, float(n)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(acc)

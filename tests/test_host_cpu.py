@@ -20,7 +20,7 @@ SID = UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=2, 
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = lib.load()
-    assert L.ucdir_abi_version() == lib.ABI_VERSION == 4
+    assert L.ucdir_abi_version() == lib.ABI_VERSION == 5
     hdr = open(os.path.join(ROOT, "include", "ucdir_hip.h")).read()
     declared = set(re.findall(r"\b(ucdir_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ucdir_ctx", "ucdir_config"}

@@ -39,7 +39,7 @@ template <int NW> struct AkWs64 {
 // LDS address: no 64-bit VALU address arithmetic per piece, and hipcc does not count it (cdna guide 5.7): the kernel waits for its DMAs at the
 // tile top by hand, and no compiler-made LDS access is held back by a vmcnt(0) for a DMA the compiler knows nothing about
 __device__ __forceinline__ void w64_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 // NPT = pixel tiles per tile (2 | 4: 64 | 128 positions); NW = waves per workgroup (8: half a group per workgroup, one workgroup per CU;

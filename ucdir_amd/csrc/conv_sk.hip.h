@@ -98,7 +98,7 @@ struct CvSk {
 // builtin always takes a per-lane 64-bit pointer).  hipcc does not count it (cdna guide 5.7): the kernel's waits are counted by hand anyway;
 // M0 (the LDS destination) is written inside the statement.
 __device__ __forceinline__ void sk_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 template <int N>

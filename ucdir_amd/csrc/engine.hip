@@ -192,13 +192,21 @@ static void launch_one(const GemmP& p, dim3 grid, size_t lds, hipStream_t st) {
 
 // Dynamic-LDS limits are a per-DEVICE function attribute: set them for every kernel instantiation once per device
 // (ucdir_create / ucdir_predictor_create / the single-operator entry points call this on the device they run on).
-template <typename K> static void set_lds_attr(K* k, int bytes) {
+// abs0: the kernel's inline-asm fragment reads use ABSOLUTE LDS byte addresses that assume the dynamic smem[] starts at LDS offset 0 (cgemm's a_ad / b_ad,
+// flash_attn2's kb2 / pa / va): true while the kernel declares no static __shared__.  Checked here once per device (round-5 advice): a static array added
+// later would shift smem[] silently and the asm reads would fetch other data.
+template <typename K> static void set_lds_attr(K* k, int bytes, bool abs0 = false) {
     HIPC(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (abs0) {
+        hipFuncAttributes fa;
+        HIPC(hipFuncGetAttributes(&fa, (const void*)k));
+        require(fa.sharedSizeBytes == 0, "a kernel with absolute LDS addressing has static __shared__ memory: its dynamic smem[] no longer starts at offset 0");
+    }
 }
 template <int TM> static void set_cgemm_attrs() {
-    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_DOWN>, 100 * 1024);
-    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_UP>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_PLAIN>, 100 * 1024);
-    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024);
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1>, 100 * 1024, true); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_DOWN>, 100 * 1024, true);
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_UP>, 100 * 1024, true); set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_PLAIN>, 100 * 1024, true);
+    set_lds_attr(cgemm_kernel<TM, EPI_STD, MODE_S1C>, 100 * 1024, true); set_lds_attr(cgemm_kernel<TM, EPI_AKGM, MODE_S1>, 100 * 1024, true);
 }
 #define SPLITK_MAX_WGS 512
 #define SK_MAX_GRID 256                            // conv_sk_kernel: two partial slots of 256 KB per workgroup
@@ -227,16 +235,16 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv_ws128_kernel, CvWs128::LDS);
     set_lds_attr(conv_sk_kernel<2, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 8, 4>, 160 * 1024);
     set_lds_attr(conv_sk_kernel<1, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<1, 8, 4>, 160 * 1024);
-    set_lds_attr(conv_sk_kernel<1, 4, 9>, 80 * 1024); set_lds_attr(conv_sk_kernel<1, 4, 4>, 80 * 1024);
+    set_lds_attr(conv_sk_kernel<1, 4, 9>, 80 * 1024, true); set_lds_attr(conv_sk_kernel<1, 4, 4>, 80 * 1024, true);
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
     set_lds_attr(flash_attn_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn_kernel<3, true>, fa_lds_bytes(384));
     set_lds_attr(flash_attn_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn_kernel<4, true>, fa_lds_bytes(512));
-    set_lds_attr(flash_attn2_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn2_kernel<1, true>, fa_lds_bytes(128));
-    set_lds_attr(flash_attn2_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn2_kernel<2, true>, fa_lds_bytes(256));
-    set_lds_attr(flash_attn2_kernel<3, false>, fa_lds_bytes(384)); set_lds_attr(flash_attn2_kernel<3, true>, fa_lds_bytes(384));
-    set_lds_attr(flash_attn2_kernel<4, false>, fa_lds_bytes(512)); set_lds_attr(flash_attn2_kernel<4, true>, fa_lds_bytes(512));
+    set_lds_attr(flash_attn2_kernel<1, false>, fa_lds_bytes(128), true); set_lds_attr(flash_attn2_kernel<1, true>, fa_lds_bytes(128), true);
+    set_lds_attr(flash_attn2_kernel<2, false>, fa_lds_bytes(256), true); set_lds_attr(flash_attn2_kernel<2, true>, fa_lds_bytes(256), true);
+    set_lds_attr(flash_attn2_kernel<3, false>, fa_lds_bytes(384), true); set_lds_attr(flash_attn2_kernel<3, true>, fa_lds_bytes(384), true);
+    set_lds_attr(flash_attn2_kernel<4, false>, fa_lds_bytes(512), true); set_lds_attr(flash_attn2_kernel<4, true>, fa_lds_bytes(512), true);
     done.insert(dev);
 }
 
@@ -858,6 +866,9 @@ static void run_akgm_halo(const AkgmW& w, const Act& h1, const float* G, const f
                 npt64 = cand; tps64 = tps;
                 lds64 = ws64_nw == 4 ? AkWs64<4>::lds(hpos) : AkWs64<8>::lds(hpos);
                 p.tw = AkWs64<4>::HBYTES(hpos);
+                // (round-5 advice) four-wave workgroups are only co-resident in pairs while two of them fit the CU's 160 KB: wide planes
+                // (hpos ~272: 90.6 KB) leave one per CU - the grid then covers one resident workgroup per CU, not two half-rounds
+                if (ws64_nw == 4 && 2 * lds64 > 160 * 1024 && g_persist_grid <= 0) { grid64 = num_cus() / nrole * nrole; if (grid64 < nrole) grid64 = nrole; }
                 break;
             }
         }
@@ -1088,11 +1099,12 @@ static void run_attention(const ConvW& wqkv, const ConvW& wout, const Act& x, Ac
         f.dbg = fdbg;
 #endif
         const dim3 grid((unsigned)(B * f.nq));
-        // flash_attn2_kernel (round 5): the two query halves of a workgroup one phase apart, 32-key tiles, K and V't double-buffered;
-        // UCDIR_FLASH1=1 / ucdir_debug_flag("flash2", 0) selects the round-2 kernel (all eight waves in one phase, 64-key tiles)
+        // flash_attn2_kernel (round 5, the default): flash_attn_kernel's structure (128 queries per workgroup, 64-key tiles, all eight waves in one
+        // phase, two barriers per tile) with every fragment read of the S and PV phases as inline asm with counted lgkmcnt; same LDS layout and size.
+        // UCDIR_FLASH1=1 / ucdir_debug_flag("flash2", 0) selects the round-2 kernel (compiler-scheduled reads)
         static const bool flash1_env = getenv("UCDIR_FLASH1") != nullptr;
         const bool flash2 = g_flash2 < 0 ? !flash1_env : g_flash2 != 0;
-        const size_t lds = flash2 ? fa_lds_bytes(C) : fa_lds_bytes(C);
+        const size_t lds = fa_lds_bytes(C);
         auto launch = [&]() {
             if (flash2) {
                 switch (C / 128 * 2 + (a.half ? 1 : 0)) {
@@ -1703,33 +1715,56 @@ int32_t ucdir_unet_forward(ucdir_ctx* ctx, const float* cond, const float* x_t, 
     API_END
 }
 
+// seeds_dev == nullptr: one stream of `seed` over the whole buffer; else B = n / per samples, sample b on the stream of seeds_dev[b]
+static void sampler_rng_launch(const char* who, float* x_t, const float* eps, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
+                               float sigma, uint64_t seed, const uint64_t* seeds_dev, int64_t per, uint32_t step, void* stream) {
+    const std::string w(who);
+    require(x_t && (eps || sigma == -1.f), "null argument");
+    require(((uintptr_t)x_t & 15) == 0 && ((uintptr_t)eps & 15) == 0, w + ": buffers must be 16-byte aligned");
+    hipPointerAttribute_t pa;
+    HIPC(hipPointerGetAttributes(&pa, x_t));
+    require(pa.type == hipMemoryTypeDevice, w + ": not a device pointer");
+    if (seeds_dev) {
+        require(per > 0 && per % 4 == 0 && n % per == 0, w + ": n must be a whole number of samples of `per` elements, per a multiple of 4");
+        hipPointerAttribute_t ps;
+        HIPC(hipPointerGetAttributes(&ps, seeds_dev));
+        require(ps.type == hipMemoryTypeDevice && ps.device == pa.device, w + ": seeds must live on the device of the buffer");
+    }
+    DevGuard dg(pa.device);
+    long long blocks = ((n + 3) / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    if (eps) hipLaunchKernelGGL(sampler_step_rng_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, eps, (long long)n,
+                                c_recip, c_recipm1, coef1, coef2, sigma, (unsigned long long)seed, step, (const unsigned long long*)seeds_dev, (long long)(per / 4));
+    else hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, (long long)n, (unsigned long long)seed, step,
+                            (const unsigned long long*)seeds_dev, (long long)(per / 4));
+    HIPC(hipGetLastError());
+}
+
 int32_t ucdir_sampler_step_rng(float* x_t, const float* eps, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
                                float sigma, uint64_t seed, uint32_t step, void* stream) {
     API_BEGIN
-    require(x_t && eps, "null argument");
-    require(((uintptr_t)x_t & 15) == 0 && ((uintptr_t)eps & 15) == 0, "ucdir_sampler_step_rng: x_t and eps must be 16-byte aligned");
-    hipPointerAttribute_t pa;
-    HIPC(hipPointerGetAttributes(&pa, x_t));
-    require(pa.type == hipMemoryTypeDevice, "ucdir_sampler_step_rng: x_t is not a device pointer");
-    DevGuard dg(pa.device);
-    long long blocks = ((n + 3) / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sampler_step_rng_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_t, eps, (long long)n,
-                       c_recip, c_recipm1, coef1, coef2, sigma, (unsigned long long)seed, step);
-    HIPC(hipGetLastError());
+    require(eps, "null argument");
+    sampler_rng_launch("ucdir_sampler_step_rng", x_t, eps, n, c_recip, c_recipm1, coef1, coef2, sigma, seed, nullptr, 0, step, stream);
     API_END
 }
 
 int32_t ucdir_fill_normal(float* x, int64_t n, uint64_t seed, uint32_t step, void* stream) {
     API_BEGIN
-    require(x, "null argument");
-    require(((uintptr_t)x & 15) == 0, "ucdir_fill_normal: x must be 16-byte aligned");
-    hipPointerAttribute_t pa;
-    HIPC(hipPointerGetAttributes(&pa, x));
-    require(pa.type == hipMemoryTypeDevice, "ucdir_fill_normal: x is not a device pointer");
-    DevGuard dg(pa.device);
-    long long blocks = ((n + 3) / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (unsigned long long)seed, step);
-    HIPC(hipGetLastError());
+    sampler_rng_launch("ucdir_fill_normal", x, nullptr, n, 0.f, 0.f, 0.f, 0.f, -1.f, seed, nullptr, 0, step, stream);
+    API_END
+}
+
+int32_t ucdir_sampler_step_rng_batched(float* x_t, const float* eps, int64_t n, int64_t per, float c_recip, float c_recipm1, float coef1, float coef2,
+                                       float sigma, const uint64_t* seeds_dev, uint32_t step, void* stream) {
+    API_BEGIN
+    require(eps && seeds_dev, "null argument");
+    sampler_rng_launch("ucdir_sampler_step_rng_batched", x_t, eps, n, c_recip, c_recipm1, coef1, coef2, sigma, 0, seeds_dev, per, step, stream);
+    API_END
+}
+
+int32_t ucdir_fill_normal_batched(float* x, int64_t n, int64_t per, const uint64_t* seeds_dev, uint32_t step, void* stream) {
+    API_BEGIN
+    require(seeds_dev, "null argument");
+    sampler_rng_launch("ucdir_fill_normal_batched", x, nullptr, n, 0.f, 0.f, 0.f, 0.f, -1.f, 0, seeds_dev, per, step, stream);
     API_END
 }
 

@@ -594,22 +594,35 @@ __device__ __forceinline__ void normal4(unsigned long long seed, uint32_t step, 
     }
 }
 // x <- N(0, 1) (x_T of a restoration); n elements, four per thread and counter
-__global__ void fill_normal_kernel(float* __restrict__ x, long long n, unsigned long long seed, uint32_t step) {
+// seeds != nullptr (round 6, ucdir_*_batched): the buffer is B samples of `per` elements (a multiple of 4), sample b draws the stream of
+// seeds[b] with counters that restart at its first element - the noise of an image does not depend on which batch it is restored in
+__device__ __forceinline__ void sample_stream(const unsigned long long* __restrict__ seeds, long long per4, long long g, unsigned long long& seed, unsigned long long& grp) {
+    if (seeds) { const long long b = g / per4; seed = seeds[b]; grp = (unsigned long long)(g - b * per4); }
+    else grp = (unsigned long long)g;
+}
+__global__ void fill_normal_kernel(float* __restrict__ x, long long n, unsigned long long seed0, uint32_t step, const unsigned long long* __restrict__ seeds, long long per4) {
     const long long ng = (n + 3) >> 2;
     for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
         float z[4];
-        normal4(seed, step, (unsigned long long)g, z);
+        unsigned long long seed = seed0, grp;
+        sample_stream(seeds, per4, g, seed, grp);
+        normal4(seed, step, grp, z);
         if (4 * g + 3 < n) *reinterpret_cast<float4*>(x + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
         else for (int e = 0; e < 4; ++e) if (4 * g + e < n) x[4 * g + e] = z[e];
     }
 }
 // the sampler update with its noise generated in registers (no noise tensor, no randn / clone launches)
 __global__ void sampler_step_rng_kernel(float* __restrict__ xt, const float* __restrict__ eps, long long n, float c_recip, float c_recipm1,
-                                        float coef1, float coef2, float sigma, unsigned long long seed, uint32_t step) {
+                                        float coef1, float coef2, float sigma, unsigned long long seed0, uint32_t step,
+                                        const unsigned long long* __restrict__ seeds, long long per4) {
     const long long ng = (n + 3) >> 2;
     for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < ng; g += (long long)gridDim.x * blockDim.x) {
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (sigma != 0.f) normal4(seed, step, (unsigned long long)g, z);
+        if (sigma != 0.f) {
+            unsigned long long seed = seed0, grp;
+            sample_stream(seeds, per4, g, seed, grp);
+            normal4(seed, step, grp, z);
+        }
         if (4 * g + 3 < n) {
             const float4 x4 = *reinterpret_cast<const float4*>(xt + 4 * g), e4 = *reinterpret_cast<const float4*>(eps + 4 * g);
             const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, es[4] = {e4.x, e4.y, e4.z, e4.w};

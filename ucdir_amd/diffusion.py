@@ -63,6 +63,9 @@ class GaussianDiffusion(nn.Module):
         self.noise_source = None     # optional callable(shape, device, k) -> tensor, for injected noise
         self.noise_seed = None       # optional int: rank-identical device generator (sharded patch split)
         self.noise_index = 0         # per-image offset of the seed (sr.py sets the dataset index before every restoration)
+        self.sample_seeds = None     # optional list of ints, one per sample of the NEXT p_sample_loop batch: every sample draws its own
+                                     # in-kernel noise stream (counters local to the sample), so an image's noise does not depend on the
+                                     # batch it is grouped into (sr.py --batch); ignored when noise is injected (noise_source)
         self._gen = None
 
     def set_loss(self, device):
@@ -189,6 +192,11 @@ class GaussianDiffusion(nn.Module):
     def _p_sample_steps(self, x, guide, sample_inter):
         self._start_noise(x.device, kernel_rng=True)
         B = x.shape[0]
+        seeds = None
+        if self.sample_seeds is not None and self.noise_source is None:
+            if len(self.sample_seeds) != B:
+                raise ValueError("sample_seeds holds %d seeds for a batch of %d" % (len(self.sample_seeds), B))
+            seeds = torch.tensor([int(v) % (2 ** 63) for v in self.sample_seeds], dtype=torch.int64, device=x.device)
         if getattr(self.denoise_fn, "use_graph", False) and self._small(x):
             # graph replay: the four tensors the denoiser sees live in buffers that persist ACROSS restorations of the
             # same shape, so the forward is captured once and replayed for every step of every image
@@ -203,13 +211,13 @@ class GaussianDiffusion(nn.Module):
             if self.noise_source is not None:
                 img.copy_(self._noise(x, 0))
             else:
-                fill_normal_(img, self._kseed, 0)
+                fill_normal_(img, self._kseed, 0, seeds=seeds)
         else:
             cond = x
             if self.noise_source is not None:
                 img = self._noise(x, 0).clone()               # x_t: ONE buffer, updated in place
             else:
-                img = fill_normal_(torch.empty_like(x), self._kseed, 0)
+                img = fill_normal_(torch.empty_like(x), self._kseed, 0, seeds=seeds)
             eps_buf = torch.empty_like(img)
             lvl = torch.empty((B, 1), dtype=torch.float32, device=x.device)
         ret = [x]
@@ -222,7 +230,7 @@ class GaussianDiffusion(nn.Module):
                 noise = self._noise(img, k) if i > 0 else None
                 sampler_step_(img, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma)
             else:                                             # noise of (seed, step k, element) generated in the update kernel
-                sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0)
+                sampler_step_rng_(img, eps, self._kseed, k, c_recip, c_recipm1, coef1, coef2, sigma if i > 0 else 0.0, seeds=seeds)
             if i > 0:
                 k += 1
             if i % sample_inter == 0:

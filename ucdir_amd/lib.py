@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCDIR_LIB") or os.path.join(_HERE, "libucdir_hip.so")   # UCDIR_LIB: A/B-test another build
 MAX_MULTS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class UcdirConfig(Structure):
@@ -41,6 +41,9 @@ _SIGS = {
     "ucdir_sampler_step_rng": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          ctypes.c_uint64, ctypes.c_uint32, c_void_p]),
     "ucdir_fill_normal": (c_int32, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint32, c_void_p]),
+    "ucdir_sampler_step_rng_batched": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                                 c_void_p, ctypes.c_uint32, c_void_p]),
+    "ucdir_fill_normal_batched": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, ctypes.c_uint32, c_void_p]),
     "ucdir_gather_windows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "ucdir_sampler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                      c_float, c_void_p]),

@@ -53,14 +53,32 @@ class DDPM:
         dn = self.netG.denoise_fn
         seed = getattr(self, "_shared_noise_seed", None)
         sharded = seed is not None and dn.patch_group is not None and sr.shape[-1] * sr.shape[-2] > dn.patch_threshold
+        idx = self.data.get("Index", 0)
+        if torch.is_tensor(idx):
+            idxs = [int(v) for v in idx.reshape(-1).tolist()]
+        elif isinstance(idx, (list, tuple)):
+            idxs = [int(v) for v in idx]
+        else:
+            idxs = [int(idx or 0)]
         if seed is not None:
             # rank-identical noise only where the ranks cooperate on one image; its seed is offset by the image index
             # (data["Index"] when the loader provides it) so that images stay independent of each other and of the world size
             self.netG.noise_seed = seed if sharded else None
-            idx = self.data.get("Index", 0)
-            self.netG.noise_index = int(idx.reshape(-1)[0]) if torch.is_tensor(idx) else int(idx or 0)
-        with torch.no_grad():
-            out = self.netG.super_resolution(sr, continous)
+            self.netG.noise_index = idxs[0]
+        base = getattr(self, "image_seed_base", None)
+        if base is not None:
+            # sr.py --batch: every image of the batch draws the in-kernel noise stream of ITS index, with counters local to the image -
+            # the same noise whether it is restored alone, in a batch of 16 or on another rank (identical on all ranks of a sharded one)
+            if len(idxs) != sr.shape[0]:
+                raise ValueError("data['Index'] must hold one index per image of the batch")
+            self.netG.sample_seeds = [int(base) + 1000003 * i for i in idxs]
+        else:
+            self.netG.sample_seeds = None
+        try:
+            with torch.no_grad():
+                out = self.netG.super_resolution(sr, continous)
+        finally:
+            self.netG.sample_seeds = None
         self.SR = out[..., pd:-pd, pd:-pd]
 
     def set_new_noise_schedule(self, schedule_opt, schedule_phase="train"):
@@ -76,14 +94,17 @@ class DDPM:
         out["LR"] = self.data["LR"].detach().float().cpu() if need_LR and "LR" in self.data else out["INF"]
         return out
 
-    def visuals_u8(self):
-        """uint8 HWC images of the val loop (final SR, HR, LR, INF = predictor output) converted ON THE DEVICE:
-        only 4 x H x W x 3 bytes cross PCIe instead of the 11 fp32 snapshots of get_current_visuals."""
+    def visuals_u8(self, j=0):
+        """uint8 HWC images of the val loop (final SR, HR, LR, INF = predictor output) of image ``j`` of the batch, converted ON THE
+        DEVICE: only 4 x H x W x 3 bytes cross PCIe instead of the 11 fp32 snapshots of get_current_visuals.
+        (``continous=True`` stacks the snapshots along dim 0 in blocks of B images: the final ones are the last block.)"""
         from .metrics import tensor2img_u8_device as cv
-        sr = self.SR[-1] if self.SR.dim() == 4 else self.SR
-        out = OrderedDict(SR=cv(sr), HR=cv(self.data["HR"]), LR=cv(self.data["LR"] if "LR" in self.data else self.data["SR"]))
+        B = self.data["SR"].shape[0]
+        sr = self.SR[self.SR.shape[0] - B + j] if self.SR.dim() == 4 else self.SR
+        lr = self.data["LR"] if "LR" in self.data else self.data["SR"]
+        out = OrderedDict(SR=cv(sr), HR=cv(self.data["HR"][j]), LR=cv(lr[j]))
         pre = getattr(self.netG, "pre_initx", None)
-        out["INF"] = cv(pre[..., 64:-64, 64:-64]) if pre is not None else cv(self.data["SR"])
+        out["INF"] = cv(pre[j, :, 64:-64, 64:-64]) if pre is not None else cv(self.data["SR"][j])
         return out
 
     def load_network(self):

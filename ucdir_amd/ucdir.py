@@ -313,14 +313,30 @@ def sampler_step_(x_t, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma):
     return x_t
 
 
-def sampler_step_rng_(x_t, eps, seed, step, c_recip, c_recipm1, coef1, coef2, sigma):
-    """The same update with the noise of (seed, step, element) generated inside the kernel (no noise tensor)."""
+def _check_seeds(seeds, x, who):
+    """Per-sample seeds: one int64 per sample of ``x`` on its device (bit pattern = the uint64 Philox key)."""
+    if not (torch.is_tensor(seeds) and seeds.is_cuda and seeds.device == x.device and seeds.dtype == torch.int64
+            and seeds.is_contiguous() and seeds.numel() == x.shape[0] and x.dim() >= 2 and (x.numel() // x.shape[0]) % 4 == 0):
+        raise _lib.UcdirError(who + ": seeds must be a contiguous int64 CUDA tensor with one entry per sample of x "
+                                    "(samples of a multiple of 4 elements)")
+
+
+def sampler_step_rng_(x_t, eps, seed, step, c_recip, c_recipm1, coef1, coef2, sigma, seeds=None):
+    """The same update with the noise of (seed, step, element) generated inside the kernel (no noise tensor).
+    ``seeds`` (int64 CUDA tensor, one per sample): every sample draws its own stream, counters local to the sample - the noise
+    of an image is then independent of the batch it is restored in (``seed`` is ignored)."""
     L = _lib.load()
     if not (x_t.is_cuda and x_t.is_contiguous() and x_t.dtype == torch.float32):
         raise _lib.UcdirError("sampler_step_rng_ needs contiguous fp32 CUDA tensors")
     eps = eps.contiguous()
     if not (eps.is_cuda and eps.dtype == torch.float32 and eps.numel() == x_t.numel()):
         raise _lib.UcdirError("sampler_step_rng_: eps must be an fp32 CUDA tensor shaped like x_t")
+    if seeds is not None:
+        _check_seeds(seeds, x_t, "sampler_step_rng_")
+        _lib.check(L.ucdir_sampler_step_rng_batched(_ptr(x_t), _ptr(eps), x_t.numel(), x_t.numel() // x_t.shape[0], float(c_recip),
+                                                    float(c_recipm1), float(coef1), float(coef2), float(sigma), _ptr(seeds), int(step),
+                                                    _stream_ptr(x_t.device)))
+        return x_t
     _lib.check(L.ucdir_sampler_step_rng(_ptr(x_t), _ptr(eps), x_t.numel(), float(c_recip), float(c_recipm1), float(coef1),
                                         float(coef2), float(sigma), int(seed) & (2 ** 64 - 1), int(step), _stream_ptr(x_t.device)))
     return x_t
@@ -340,11 +356,16 @@ def gather_windows(x, pad, win_dev, skip):
     return out
 
 
-def fill_normal_(x, seed, step=0):
-    """x <- N(0, 1) from the sampler's counter-based generator (x_T = step 0 of the stream the update kernel draws from)."""
+def fill_normal_(x, seed, step=0, seeds=None):
+    """x <- N(0, 1) from the sampler's counter-based generator (x_T = step 0 of the stream the update kernel draws from);
+    ``seeds``: per-sample streams as in ``sampler_step_rng_``."""
     L = _lib.load()
     if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
         raise _lib.UcdirError("fill_normal_ needs a contiguous fp32 CUDA tensor")
+    if seeds is not None:
+        _check_seeds(seeds, x, "fill_normal_")
+        _lib.check(L.ucdir_fill_normal_batched(_ptr(x), x.numel(), x.numel() // x.shape[0], _ptr(seeds), int(step), _stream_ptr(x.device)))
+        return x
     _lib.check(L.ucdir_fill_normal(_ptr(x), x.numel(), int(seed) & (2 ** 64 - 1), int(step), _stream_ptr(x.device)))
     return x
 
