@@ -35,7 +35,7 @@ KEY_NAMES = {0: "cgemm<64,std,s1>", 1: "cgemm<64,std,down>", 2: "cgemm<64,std,up
              4: "cgemm<64,std,s1c>", 10: "cgemm<64,akgm>", 11: "akgm64_halo", 20: "conv3x3_halo<64>", 22: "conv3x3_halo<64>+res", 120: "conv3x3_halo<128>", 21: "upconv_halo<64>", 121: "upconv_halo<128>", 100: "cgemm<128,std,s1>", 101: "cgemm<128,std,down>",
              102: "cgemm<128,std,up>", 103: "cgemm<128,std,plain>", 104: "cgemm<128,std,s1c>", 110: "cgemm<128,akgm>", 111: "akgm_halo", 112: "akgm_pre",
              105: "qkv_ws", 113: "akgm_ws<8>", 114: "akgm_ws<16>", 115: "akgm_ws32", 116: "akgm_ws64", 23: "conv_ws<64>", 24: "conv_ws<128->64>+res",
-             125: "conv_sk<8 waves>", 126: "upconv_sk<8 waves>", 127: "conv_sk<4 waves>+res", 128: "upconv_sk<4 waves>",
+             125: "conv_sk<8 waves>", 126: "upconv_sk<8 waves>", 127: "conv_sk<4 waves>+res", 128: "upconv_sk<4 waves>", 129: "conv_sk_mix<wide+narrow>+res",
              130: "flash_attn<bf16>", 131: "flash_attn<fp16>"}
 
 

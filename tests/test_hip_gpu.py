@@ -126,10 +126,12 @@ def test_conv_stream_k(args, kind):
     L = C.ulib.load()
     C.ulib.check(L.ucdir_debug_flag(b"convsk", kind))
     C.ulib.check(L.ucdir_debug_flag(b"persist_grid", grid))
+    C.ulib.check(L.ucdir_debug_flag(b"skmix", 0))            # the plain kernel (level3_b16 would take the mixed one: its own test below)
     try:
         (m, keys) = _profile_keys(L, lambda: C.conv_case(B, H, W, c0, c1, cout, 3, mode, gn, silu, residual, seed=5))
         m2 = C.conv_case(B, H, W, c0, c1, cout, 3, mode, gn, silu, residual, seed=5)
     finally:
+        C.ulib.check(L.ucdir_debug_flag(b"skmix", -1))
         C.ulib.check(L.ucdir_debug_flag(b"persist_grid", 0))
         C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
     assert (125 if kind == 1 else 127) + (1 if mode == 2 else 0) in keys, keys      # the new kernel ran, not a fallback
@@ -159,6 +161,41 @@ def test_conv_stream_k_with_res_conv(args):
         C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
     assert 127 in keys and 100 not in keys and 0 not in keys, keys     # one launch: no separate 1x1 GEMM
     assert not m["nan"] and m["rel_rms"] < OP_TOL and not m["res_nan"] and m["res_rel_rms"] < OP_TOL, m
+    assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0) and m["stats_rel"] < 1e-3, m
+    assert m2 == m, (m, m2)
+
+
+@pytest.mark.parametrize("args", [
+    # B, H, W, c0, c1, cout, residual, with res_conv, forced
+    (2, 24, 40, 64, 0, 256, False, False, 1),        # two row tiles: 4 wide tiles + narrow tiles behind them, ragged end, all nine border classes
+    (3, 18, 18, 128, 64, 512, False, True, 1),       # cat input, four row tiles, tiles spanning samples, the block's res_conv units behind the narrow ones
+    (2, 36, 36, 256, 0, 512, True, False, 1),        # residual
+    (2, 50, 70, 64, 0, 128, False, False, 1),        # one row tile (8 wide + narrow tiles in multiples of 8), two strips, tiles past the end of the space
+    (16, 36, 36, 512, 0, 512, False, False, -1),     # the bench configuration's 36^2 level: engages by its own occupancy rule (344 units on 512 slots)
+    (16, 36, 36, 512, 256, 512, False, True, -1),    # ... with the res_conv tail
+], ids=["fold_ragged", "cat_res_conv", "residual", "strips_rows128", "level3_b16", "level3_b16_res_conv"])
+def test_conv_sk_mixed_wide_and_narrow_units(args):
+    """conv_sk_mix_kernel (round 6): wide units (128 rows x 256 positions, four waves) and narrow units (128 x 128, the same wave tile in
+    two waves) of ONE launch against torch - the narrow tiles start where the wide ones end, halo positions behind the end of the
+    space wrap to sample 0's border - incl. the res_conv tail; profiler key 129 = the mixed kernel ran; run to run bit-identical."""
+    B, H, W, c0, c1, cout, residual, with_res, force = args
+    L = C.ulib.load()
+    C.ulib.check(L.ucdir_debug_flag(b"convsk", 2))
+    C.ulib.check(L.ucdir_debug_flag(b"skmix", force))
+    try:
+        if with_res:
+            (m, keys) = _profile_keys(L, lambda: C.conv_res_case(B, H, W, c0, c1, cout, seed=7))
+            m2 = C.conv_res_case(B, H, W, c0, c1, cout, seed=7)
+        else:
+            (m, keys) = _profile_keys(L, lambda: C.conv_case(B, H, W, c0, c1, cout, 3, 0, True, True, residual, seed=5))
+            m2 = C.conv_case(B, H, W, c0, c1, cout, 3, 0, True, True, residual, seed=5)
+    finally:
+        C.ulib.check(L.ucdir_debug_flag(b"skmix", -1))
+        C.ulib.check(L.ucdir_debug_flag(b"convsk", -1))
+    assert 129 in keys and 127 not in keys and 100 not in keys, keys
+    assert not m["nan"] and m["rel_rms"] < OP_TOL, m
+    if with_res:
+        assert not m["res_nan"] and m["res_rel_rms"] < OP_TOL, m
     assert m["max_abs_border"] < 0.05 * max(m["ref_rms"], 1.0) and m["stats_rel"] < 1e-3, m
     assert m2 == m, (m, m2)
 
@@ -500,7 +537,7 @@ def test_forward_bench_dispatch_vs_oracle_and_reference(golden_dir, sid_net, B):
         torch.cuda.synchronize()
         return e.cpu()
     eps, keys = _profile_keys(L, fwd)
-    want = [113, 114, 115, 116, 23, 24, 105]
+    want = [113, 114, 115, 116, 23, 24, 105, 127, 128, 129]   # (129: conv_sk_mix_kernel - the 36^2 level at B = 16, the 72^2 level at B = 8)
     assert all(k in keys for k in want), (sorted(keys), want)
     assert bool(torch.isfinite(eps).all())
     for b in (0, B - 1):

@@ -556,7 +556,7 @@ def test_sr_val_batches_same_sized_images(tmp_path, monkeypatch):
     rs = np.random.RandomState(3)
     for d in ("lq", "gt"):
         os.makedirs(tmp_path / d)
-    sizes = [(72, 88)] * 3 + [(64, 96)] + [(72, 88)] * 2
+    sizes = [(72, 88)] * 3 + [(80, 72)] + [(72, 88)] * 2
     for i, (h, w) in enumerate(sizes):
         gt = (rs.rand(h // 8, w // 8, 3) * 255).astype(np.uint8).repeat(8, 0).repeat(8, 1)
         Image.fromarray(gt).save(tmp_path / "gt" / f"{i:03d}.png")
@@ -585,7 +585,7 @@ def test_sr_val_batches_same_sized_images(tmp_path, monkeypatch):
         res[tag] = sr.main(["-p", "val", "-c", str(tmp_path / "sid_small.yaml"), "--synthetic-weights", "--batch", batch, "--seed", "7"])
         res[tag + "_calls"] = list(calls)
         res[tag + "_files"] = {f: os.path.join(dp, f) for dp, _, fs in os.walk(wd / "experiments") for f in fs if f.endswith("_sr.jpg")}
-    assert sorted(res["grouped_calls"]) == sorted([(5, 3, 72, 88), (1, 3, 64, 96)]), res["grouped_calls"]
+    assert sorted(res["grouped_calls"]) == sorted([(5, 3, 72, 88), (1, 3, 80, 72)]), res["grouped_calls"]
     assert len(res["single_calls"]) == 6 and all(c[0] == 1 for c in res["single_calls"])
     assert sorted(res["grouped_files"]) == sorted(res["single_files"]) and len(res["grouped_files"]) == 6
     for f in res["grouped_files"]:

@@ -41,8 +41,12 @@ struct ConvSkP {
     const bf16_t* B0; const bf16_t* B1; int c0, ld0, ld1;   // input(s), zero-bordered NHWC; channels [0, c0) from B0, the rest from B1
     int nchunks;                                      // 32-channel chunks = C_in / 32
     int nb, H, W, Wp, Hp;                             // input grid (= output grid; low-res grid for the Upsample parity classes)
-    // position space: [sample][strip][H + 2][Ws + 2] - the image is cut into ns vertical strips of Ws columns, each carried with its
-    // two neighbour columns (ns = 1: the zero-bordered tensor itself); npos = nb * ns * HpWpe positions, tiles are NPX consecutive ones
+    // position space: [sample][strip][HR][Wpe] - the image is cut into ns vertical strips of Ws columns, each carried with its two neighbour
+    // columns; npos = nb * ns * HpWpe positions (HpWpe = HR * Wpe), tiles are NPX consecutive ones.  Classic: HR = H + 2, Wpe = Ws + 2 (ns = 1:
+    // the zero-bordered tensor itself).  Round 6, SHARED BORDERS (default): HR = H + 1 - a sample's bottom border row IS the next (sample,
+    // strip)'s top border row (both zeros: row yp = 0 of the space, any tensor's padded row 0) - and with a single strip Wpe = W + 1: a row's
+    // right border pixel IS the next row's left border pixel (padded column 0).  Taps stay uniform shifts of ky Wpe + kx; the decode below is
+    // unchanged (yp = 0 .. H, xs = 0 .. Wpe - 1 are padded coordinates).  Computed-and-dropped positions: 36^2 10.3 -> 5.3 %, 18^2 19 -> 10.2 %.
     int ns, Ws, Wpe, HpWpe, npos;
     float inv_per_b, inv_HpWpe, inv_Wpe;               // reciprocals for sk_udiv (1 / (ns * HpWpe), 1 / HpWpe, 1 / Wpe)
     int ntiles, rowtiles, npar;                       // pixel tiles, row tiles, parity classes (1 | 4); units = npar * rowtiles * ntiles
@@ -61,6 +65,9 @@ struct ConvSkP {
     // out2 = res_conv(x) + bias2, unit (row tile, pixel tile) - dispatched last, they fill the workgroup slots the 3x3 conv's last,
     // partly empty round leaves idle instead of re-reading x in a launch of their own
     int alt_units; const bf16_t* alt_A; const float* alt_bias; bf16_t* alt_out; int alt_out_ld;
+    // conv_sk_mix_kernel: units (= ndp) wide units over mix_wt tiles of 256 positions, then mix_nunits (= mix_nndp) narrow units over mix_nt tiles of
+    // 128 positions from position mix_q0 = 256 mix_wt on; mix_nhp halo pieces per chunk of a narrow tile
+    int mix_wt, mix_nt, mix_nhp, mix_nunits, mix_nndp, mix_q0;
     unsigned long long* dbg;
 };
 
@@ -167,7 +174,7 @@ __device__ __forceinline__ stat_t wave_sum_ll_dpp(stat_t v) {
 // or from partial tiles gives the same bits for the same accumulator values.
 template <int MW, int NW, int TAB, bool MS_ASM>
 __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[4][2],
-                                            int par, int rt, int tile, int wm, int wn, int lane, unsigned tab_base = 0, int fsel = -1) {
+                                            int par, int rt, int q0, int wm, int wn, int lane, unsigned tab_base = 0, int fsel = -1) {
     using L = CvSk<MW, NW>;
     const int hh = lane >> 5, l31 = lane & 31;
     const int act = p.act;
@@ -176,7 +183,7 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
     stat_t sf1[2] = {0, 0}, sf2[2] = {0, 0};
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int q = tile * L::NPX + wn * 64 + n * 32 + l31;          // position in [B][strip][H + 2][Ws + 2]
+        const int q = q0 + wn * 64 + n * 32 + l31;                     // position in the strip space (q0: the unit's first position)
         int b, yp, xs, xp;
         sk_decode(p, q, b, yp, xs, xp);
         const bool valid = q < p.npos && yp >= 1 && yp <= p.H && xs >= 1 && xs <= p.Ws && xp <= p.W;
@@ -434,27 +441,17 @@ __device__ __forceinline__ void sk_alt_unit(const ConvSkP& p, unsigned char* sme
     }
 }
 
+// The schedule of one workgroup: `lid` of `G` workgroups over `units` units (the first `ndp` whole, round-robin; the rest as stream-K chunk
+// ranges), units laid over the position space from position `qbase` on in tiles of NPX, `nhp` halo pieces per chunk.  conv_sk_kernel passes the
+// launch's own figures; conv_sk_mix_kernel (below) runs a WIDE body <1, 4> and a NARROW body <1, 2> in one launch.
 template <int MW, int NW, int NTAPS>
-__global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
+__device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* smem, const int lid, const int G, const int units_arg, const int ndp_arg,
+                                             const int qbase, const int nhp) {
     using L = CvSk<MW, NW>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWN = L::NWN;                                      // waves along the pixel dimension
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
-    int lid, G;
-    {
-        int nblk = gridDim.x, bid = blockIdx.x;
-        bool alt = false;
-        if (MW == 1 && NW == 4 && p.alt_units) {                     // the grid's last workgroups: the block's 1x1 res_conv
-            const int nmain = nblk - p.alt_units;
-            if (bid >= nmain) { alt = true; bid -= nmain; nblk = p.alt_units; } else nblk = nmain;
-        }
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        G = nblk;
-        if (MW == 1 && NW == 4) { if (alt) { sk_alt_unit<NW>(p, smem, lid, wave, lane); return; } }
-    }
 #ifdef UCDIR_TIMING
     // two stamped workgroups: one of the first round (entries 0 ..), one of the last (entries 128 ..)
     const bool dbg_on = p.dbg && (lid == G / 2 + 3 || lid == G - 3) && (lane == 0) && (wave == NW - 1);
@@ -462,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     int dbg_n = 0;
 #endif
     SK_STAMP();
-    const int Wp = p.Wpe, nch = p.nchunks, nhp = p.nhp;              // (Wp: row pitch of the strip space)
+    const int Wp = p.Wpe, nch = p.nchunks;                           // (Wp: row pitch of the strip space)
     const int HB = nhp * 1024;                                       // bytes of one halo buffer
     constexpr int NHW = L::NHW;                                      // halo pieces per wave and chunk
     constexpr int TA = NTAPS - 3 > 1 ? NTAPS - 3 : 1;                // sub-steps of a chunk whose S point may carry halo pieces: the
@@ -495,9 +492,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     const unsigned hsw = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 3);
     auto piece_of = [&](int j) { const int i = j * NW + wave; return i < nhp ? i : nhp - 1; };
 
-    const SkSched sch(p.units, p.ndp, nch, G);
+    const SkSched sch(units_arg, ndp_arg, nch, G);
     const long long c_beg = sch.start(lid), c_end = sch.start(lid + 1);      // stream-K chunk range of this workgroup
-    const int ndp_mine = lid < p.ndp ? (p.ndp - lid + G - 1) / G : 0;        // whole units lid, lid + G, ...
+    const int ndp_mine = lid < ndp_arg ? (ndp_arg - lid + G - 1) / G : 0;    // whole units lid, lid + G, ...
     long long cpos = c_beg;
     int dpi = 0;
     struct Seg { int unit, cb, ce, par, rt, tile; bool first_sk, ok; };
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         if (dpi < ndp_mine) { s.unit = lid + dpi * G; s.cb = 0; s.ce = nch; ++dpi; }
         else if (cpos < c_end) {
             const long long u = cpos / nch;
-            s.unit = p.ndp + (int)u; s.cb = (int)(cpos - u * nch);
+            s.unit = ndp_arg + (int)u; s.cb = (int)(cpos - u * nch);
             const long long e = (u + 1) * nch < c_end ? (u + 1) * nch : c_end;
             s.ce = (int)(e - u * nch);
             s.first_sk = cpos == c_beg;
@@ -562,11 +559,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     int hb0 = 0;                                                     // halo buffer of the segment's first chunk
     auto prefetch = [&](const Seg& s) {                              // halo of the first chunk and stages 0 .. 3 of segment s
         if (NTAPS != 9) set_bx(s.par >> 1, s.par & 1);
-        const int q0 = s.tile * L::NPX;
+        const int q0 = qbase + s.tile * L::NPX;
 #pragma unroll
         for (int j = 0; j < NHW; ++j) {
             int q = q0 + hpos0 + 16 * piece_of(j);
-            q = q < 0 ? 0 : (q >= p.npos ? p.npos - 1 : q);
+            // in front of the space: position 0 (a border pixel); behind it: the positions of a virtual further sample, read from sample 0 -
+            // its row 0 and the first pixel of its row 1 are border zeros, which is all a VALID position's taps can reach (shared-border
+            // space: the last position is an interior pixel, a clamp to it would hand its value to the bottom taps of the last row)
+            q = q < 0 ? 0 : (q >= p.npos ? (q - p.npos < p.npos ? q - p.npos : 0) : q);
             int b, yp, xs, xp;
             sk_decode(p, q, b, yp, xs, xp);
             xp = xp < p.Wp ? xp : p.Wp - 1;                          // (a ragged last strip)
@@ -591,8 +591,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     // (alpha * rstd, mean * rstd): persistent workgroups build the whole list once, one-shot ones the few samples their tile spans
     auto sample_range = [&](const Seg& s) {
         const int per_b = p.ns * p.HpWpe;
-        const int b0 = sk_udiv(s.tile * L::NPX, per_b, p.inv_per_b);
-        int b1 = sk_udiv(s.tile * L::NPX + L::NPX - 1, per_b, p.inv_per_b) + 1; b1 = b1 < p.nb ? b1 : p.nb;
+        const int b0 = sk_udiv(qbase + s.tile * L::NPX, per_b, p.inv_per_b);
+        int b1 = sk_udiv(qbase + s.tile * L::NPX + L::NPX - 1, per_b, p.inv_per_b) + 1; b1 = b1 < p.nb ? b1 : p.nb;
         if (b0 < b1) sk_sample_table(p, reinterpret_cast<float*>(smem + L::OFF_MS) + 2 * b0, b0, b1, wave, NW, lane);
     };
     if (L::LDS_TAB) {
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         __builtin_amdgcn_sched_barrier(0);
 
         if (cb == 0 && ce == nch) {
-            sk_epilogue<MW, NW, L::LDS_TAB ? 1 : 2, true>(p, smem, nullptr, acc, cur.par, cur.rt, cur.tile, wm, wn, lane, tab_base);
+            sk_epilogue<MW, NW, L::LDS_TAB ? 1 : 2, true>(p, smem, nullptr, acc, cur.par, cur.rt, qbase + cur.tile * L::NPX, wm, wn, lane, tab_base);
         } else {
             // raw accumulators, accumulator layout: [wave][f][n][reg / 4][lane][4] fp32 - coalesced 16-byte stores
             float* pw = p.partial + ((long long)(2 * lid + (cur.first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
@@ -767,6 +767,67 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     }
 #ifdef UCDIR_TIMING
     if (dbg_on) p.dbg[dbg_off ? 254 : 255] = dbg_n;
+#endif
+}
+
+template <int MW, int NW, int NTAPS>
+__global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int lid, G;
+    {
+        int nblk = gridDim.x, bid = blockIdx.x;
+        bool alt = false;
+        if (MW == 1 && NW == 4 && p.alt_units) {                     // the grid's last workgroups: the block's 1x1 res_conv
+            const int nmain = nblk - p.alt_units;
+            if (bid >= nmain) { alt = true; bid -= nmain; nblk = p.alt_units; } else nblk = nmain;
+        }
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        G = nblk;
+        if (MW == 1 && NW == 4) {
+            if (alt) {
+                const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                sk_alt_unit<NW>(p, smem, lid, wave, lane);
+                return;
+            }
+        }
+    }
+    conv_sk_body<MW, NW, NTAPS>(p, smem, lid, G, p.units, p.ndp, 0, p.nhp);
+}
+
+// WIDE and NARROW units in one launch (round 6: the 36^2 level at B = 16).  364 units of 128 rows x 256 positions on 512 resident slots leave 148
+// CUs with ONE workgroup (a unit takes ~96 us alone and ~180 us beside a second one: the launch takes the 180).  Here the position space is cut
+// into mix_wt WIDE tiles of 256 positions (four waves) followed by mix_nt NARROW tiles of 128 positions (the same 128 x 64 wave tile and K loop
+// in TWO waves; waves 2 - 3 of the workgroup exit at once) such that (mix_wt + mix_nt) * rowtiles = 2 x CUs: every CU gets exactly two
+// workgroups, a wide and a narrow one or two narrow ones - 1.5 instead of 2 units of work on the busiest CU.  Order: XCD x gets the x-th eighth
+// of the wide units, then the x-th eighth of the narrow ones (both multiples of 8); within an XCD workgroups are handed out in blockIdx order
+// and every CU takes one before any takes a second (tools/micro/dispatch_map.hip), so the wide ones, dispatched first, land on different CUs.
+// The block's res_conv units stay wide and stay the grid's tail.
+template <int NTAPS>
+__global__ __launch_bounds__(256, 2) void conv_sk_mix_kernel(const ConvSkP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nmain = (int)gridDim.x - p.alt_units;
+    int bid = blockIdx.x;
+    if (bid >= nmain) {                                              // res_conv tail, as in conv_sk_kernel
+        bid -= nmain;
+        const int nblk = p.alt_units, q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        sk_alt_unit<4>(p, smem, lid, wave, lane);
+        return;
+    }
+    // (units and whole-unit counts come from separate fields of p although the host sets them equal: with `ndp == units == G` visible at compile
+    // time hipcc folds the segment loop away and the code that is left spills 56 - 125 registers; this way the bodies compile as in conv_sk_kernel)
+    const int wu = p.units, nu = p.mix_nunits;                       // wide / narrow units (multiples of 8)
+    const int xcd = bid & 7, j = bid >> 3, wpx = wu >> 3, npx = nu >> 3;
+#ifdef SK_MIX_ONLY_NARROW
+    if (j < wpx) return;
+#else
+    if (j < wpx) { conv_sk_body<1, 4, NTAPS>(p, smem, xcd * wpx + j, wu, wu, p.ndp, 0, p.nhp); return; }
+#endif
+#ifndef SK_MIX_ONLY_WIDE
+    if (threadIdx.x >= 128) return;                                  // (s_barrier counts the workgroup's live waves only)
+    conv_sk_body<1, 2, NTAPS>(p, smem, xcd * npx + (j - wpx), nu, nu, p.mix_nndp, p.mix_q0, p.mix_nhp);
 #endif
 }
 
@@ -852,5 +913,5 @@ __global__ __launch_bounds__(64) void conv_sk_finish_kernel(const ConvSkP p, int
         }
     }
     __syncthreads();
-    sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile, wm, wn, lane, 0, fsel);
+    sk_epilogue<MW, NW, 0, false>(p, nullptr, ms, acc, par, rt, tile * L::NPX, wm, wn, lane, 0, fsel);
 }
