@@ -168,16 +168,17 @@ def test_conv_stream_k_with_res_conv(args):
 @pytest.mark.parametrize("args", [
     # B, H, W, c0, c1, cout, residual, with res_conv, forced
     (2, 24, 40, 64, 0, 256, False, False, 1),        # two row tiles: 4 wide tiles + narrow tiles behind them, ragged end, all nine border classes
-    (3, 18, 18, 128, 64, 512, False, True, 1),       # cat input, four row tiles, tiles spanning samples, the block's res_conv units behind the narrow ones
+    (3, 18, 18, 128, 64, 512, False, True, 1),       # cat input, four row tiles, tiles spanning samples, the block's res_conv units behind the short ones
     (2, 36, 36, 256, 0, 512, True, False, 1),        # residual
-    (2, 50, 70, 64, 0, 128, False, False, 1),        # one row tile (8 wide + narrow tiles in multiples of 8), two strips, tiles past the end of the space
+    (2, 50, 70, 64, 0, 128, False, False, 1),        # one row tile (8 wide tiles, short tiles in multiples of 4), two strips, tiles past the end of the space
     (16, 36, 36, 512, 0, 512, False, False, -1),     # the bench configuration's 36^2 level: engages by its own occupancy rule (344 units on 512 slots)
     (16, 36, 36, 512, 256, 512, False, True, -1),    # ... with the res_conv tail
 ], ids=["fold_ragged", "cat_res_conv", "residual", "strips_rows128", "level3_b16", "level3_b16_res_conv"])
-def test_conv_sk_mixed_wide_and_narrow_units(args):
-    """conv_sk_mix_kernel (round 6): wide units (128 rows x 256 positions, four waves) and narrow units (128 x 128, the same wave tile in
-    two waves) of ONE launch against torch - the narrow tiles start where the wide ones end, halo positions behind the end of the
-    space wrap to sample 0's border - incl. the res_conv tail; profiler key 129 = the mixed kernel ran; run to run bit-identical."""
+def test_conv_sk_mixed_wide_and_short_units(args):
+    """conv_sk_kernel<1, 4, 9> with a mixed schedule (round 6): wide units (128 rows x 256 positions, wave tile 128 x 64) over the first
+    pixel tiles and SHORT units (64 rows x 256 positions, wave tile 64 x 64, two per 128-row tile) over the rest of ONE launch against
+    torch - halo positions behind the end of the space wrap to sample 0's border - incl. the res_conv tail; profiler key 129 = the
+    mixed schedule ran; run to run bit-identical."""
     B, H, W, c0, c1, cout, residual, with_res, force = args
     L = C.ulib.load()
     C.ulib.check(L.ucdir_debug_flag(b"convsk", 2))
@@ -537,7 +538,7 @@ def test_forward_bench_dispatch_vs_oracle_and_reference(golden_dir, sid_net, B):
         torch.cuda.synchronize()
         return e.cpu()
     eps, keys = _profile_keys(L, fwd)
-    want = [113, 114, 115, 116, 23, 24, 105, 127, 128, 129]   # (129: conv_sk_mix_kernel - the 36^2 level at B = 16, the 72^2 level at B = 8)
+    want = [113, 114, 115, 116, 23, 24, 105, 127, 128, 129]   # (129: conv_sk_kernel<1,4,9> with wide + short units - the 36^2 level at B = 16, the 72^2 level at B = 8)
     assert all(k in keys for k in want), (sorted(keys), want)
     assert bool(torch.isfinite(eps).all())
     for b in (0, B - 1):

@@ -65,8 +65,8 @@ struct ConvSkP {
     // out2 = res_conv(x) + bias2, unit (row tile, pixel tile) - dispatched last, they fill the workgroup slots the 3x3 conv's last,
     // partly empty round leaves idle instead of re-reading x in a launch of their own
     int alt_units; const bf16_t* alt_A; const float* alt_bias; bf16_t* alt_out; int alt_out_ld;
-    // conv_sk_mix_kernel: units (= ndp) wide units over mix_wt tiles of 256 positions, then mix_nunits (= mix_nndp) narrow units over mix_nt tiles of
-    // 128 positions from position mix_q0 = 256 mix_wt on; mix_nhp halo pieces per chunk of a narrow tile
+    // mixed launch (conv_sk_kernel<1, 4, 9>, mix_nunits > 0): units (= ndp) wide units over the first mix_wt pixel tiles, then mix_nunits (= mix_nndp) SHORT units (64 rows: two per
+    // 128-row tile) over the mix_nt pixel tiles from position mix_q0 = 256 mix_wt on
     int mix_wt, mix_nt, mix_nhp, mix_nunits, mix_nndp, mix_q0;
     unsigned long long* dbg;
 };
@@ -172,9 +172,9 @@ __device__ __forceinline__ stat_t wave_sum_ll_dpp(stat_t v) {
 // Shared by the conv kernel (LDS_TAB: fold tables and per-sample scalars in LDS, read by uncounted inline asm) and the finish kernel
 // (tables straight from bias / Tb / Tg in global memory, scalars in its own LDS): identical arithmetic - a unit finished in-kernel
 // or from partial tiles gives the same bits for the same accumulator values.
-template <int MW, int NW, int TAB, bool MS_ASM>
-__device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[4][2],
-                                            int par, int rt, int q0, int wm, int wn, int lane, unsigned tab_base = 0, int fsel = -1) {
+template <int MW, int NW, int TAB, bool MS_ASM, int NF = 4>
+__device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned char* smem, const float* ms_plain, f32x16_t (&acc)[NF][2],
+                                            int par, int rt, int q0, int wm, int wn, int lane, unsigned tab_base = 0, int fsel = -1, int roff = 0) {
     using L = CvSk<MW, NW>;
     const int hh = lane >> 5, l31 = lane & 31;
     const int act = p.act;
@@ -203,9 +203,9 @@ __device__ __forceinline__ void sk_epilogue(const ConvSkP& p, const unsigned cha
         if (p.npar > 1) opos = ((long long)b * (2 * p.H + 2) + (2 * y + py + 1)) * (2 * p.W + 2) + (2 * x + pxp + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < NF; ++f) {
             if (fsel >= 0 && f != fsel) continue;                      // (finish kernel: one 32-row fragment per workgroup)
-            const int ch = wm * 128 + f * 32 + 16 * hh;                // channel within the row tile
+            const int ch = wm * 128 + roff + f * 32 + 16 * hh;         // channel within the 128-row tile (roff: a SHORT unit's half, 0 | 64)
             const int fo = rt * L::ROWS + ch;
             f32x4_t b4[4], g4v[4];
             if (TAB == 2) {
@@ -443,11 +443,17 @@ __device__ __forceinline__ void sk_alt_unit(const ConvSkP& p, unsigned char* sme
 
 // The schedule of one workgroup: `lid` of `G` workgroups over `units` units (the first `ndp` whole, round-robin; the rest as stream-K chunk
 // ranges), units laid over the position space from position `qbase` on in tiles of NPX, `nhp` halo pieces per chunk.  conv_sk_kernel passes the
-// launch's own figures; conv_sk_mix_kernel (below) runs a WIDE body <1, 4> and a NARROW body <1, 2> in one launch.
-template <int MW, int NW, int NTAPS>
+// launch's own figures; a mixed launch (below) runs wide units and SHORT units (NF = 2) side by side.
+// NF = 4: the wave tile is 128 rows x 64 positions; NF = 2: SHORT units - 64 rows (one half of a 128-row tile: the upper or lower 4 KB of every 8 KB
+// stage of the packed image, the parent tile's fold tables) x the same positions, wave tile 64 x 64: half the matrix work per wave at the same halo,
+// the quantum a mixed launch balances the SIMDs with.
+template <int MW, int NW, int NTAPS, int NF = 4>
 __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* smem, const int lid, const int G, const int units_arg, const int ndp_arg,
                                              const int qbase, const int nhp) {
     using L = CvSk<MW, NW>;
+    static_assert(NF == 4 || (NF == 2 && MW == 1 && NW == 4), "short units: four waves of 64 x 64");
+    constexpr int PWN = L::PW * NF / 4;                              // DMA pieces per wave and stage
+    constexpr int RSUB = 4 / NF;                                     // units per 128-row tile
     constexpr int NWN = L::NWN;                                      // waves along the pixel dimension
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -469,7 +475,8 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
 
     // ---- per-lane constants of the fragment reads ------------------------------------------------------------------------
     // A: stage slot s, fragment f (32 rows), k16 j: 1 KB lane-linear at s * STAGE + ((4 wm + f) * 2 + j) * 1024 + lane * 16
-    const unsigned a_lane = L::OFF_W + (4 * wm) * 2048 + lane * 16;
+    // (short units: their 4 KB - fragments 0, 1 of the slot - sit at the slot's start)
+    const unsigned a_lane = L::OFF_W + (NF == 4 ? (4 * wm) * 2048 : 0) + lane * 16;
     // B: tap t, MFMA tile n: halo position hp = 64 wn + 32 n + l31 + ky Wp + kx; 64 bytes per position, 16-byte chunk
     // (2 jj + hh) ^ ((hp >> 2) & 3): address(jj = 1) = address(jj = 0) ^ 32.  (Upsample parity classes: per segment.)
     // (the second MFMA tile of a wave is 32 positions = 2048 bytes further with the same swizzle: an immediate offset, not a register)
@@ -510,12 +517,13 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
             cpos = e;
         } else { s.ok = false; s.unit = 0; s.cb = 0; s.ce = 0; }
         int u = s.unit;
-        const int per_par = p.rowtiles * p.ntiles;
+        const int RT = p.rowtiles * RSUB;                             // units per pixel tile
+        const int per_par = RT * p.ntiles;
         s.par = 0;
         if (p.npar > 1) { s.par = u / per_par; u -= s.par * per_par; }
         // row tile fastest: the row tiles of one pixel tile are neighbours in the (XCD-contiguous) unit order, so they run at the same time on
         // one XCD and share its halo in that L2 (row tile slowest re-read every halo C_out / 128 times from the fabric: 2.2 x the algorithmic bytes)
-        s.tile = u / p.rowtiles; s.rt = u - s.tile * p.rowtiles;
+        s.tile = u / RT; s.rt = u - s.tile * RT;                       // (s.rt counts units of 32 NF rows)
         return s;
     };
 
@@ -542,8 +550,8 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
     };
     auto issue_stage = [&](int k, int slot) {                        // stage k of the segment's (parity, row tile); past its end: whatever follows
 #pragma unroll                                                       // in the image (the image is padded by four stages) into a slot nobody reads any more
-        for (int j = 0; j < L::PW; ++j)
-            sk_dma16(a_seg + (long long)k * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + slot * L::STAGE + (wave * L::PW + j) * 1024));
+        for (int j = 0; j < PWN; ++j)
+            sk_dma16(a_seg + (long long)k * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + slot * L::STAGE + (wave * PWN + j) * 1024));
     };
     // one-shot kind: the fold tables of the segment's row tile (bias | Tb[9] | Tg[9], 128 floats each: 19 half pieces) take the place of the
     // halo pieces that the last chunk would request for a chunk that does not exist - same instruction count, idle halo buffer
@@ -576,7 +584,8 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
 #pragma unroll
         for (int j = 0; j < NHW; ++j) hq[j] = (hq[j] * (unsigned)ld_cur + hsw) * 2u;
         halo_chunk(s.cb);
-        a_seg = reinterpret_cast<const unsigned char*>(p.A + (long long)s.par * p.a_par_stride + ((long long)s.rt * nch * NTAPS) * (L::STAGE / 2) + (wave * L::PW) * 512);
+        a_seg = reinterpret_cast<const unsigned char*>(p.A + (long long)s.par * p.a_par_stride + ((long long)(s.rt / RSUB) * nch * NTAPS) * (L::STAGE / 2) +
+                                                       (s.rt % RSUB) * (L::STAGE / 2 / RSUB) + (wave * PWN) * 512);
         seg_cb = s.cb;
 #pragma unroll
         for (int j = 0; j < NHW; ++j) issue_halo(j, hb0);
@@ -604,9 +613,9 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
     while (true) {
         const Seg nxt = next_segment();
         const int cb = cur.cb, ce = cur.ce;
-        f32x16_t acc[4][2];
+        f32x16_t acc[NF][2];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -617,15 +626,17 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         SK_STAMP();
 
-        bf16x8_t fa[2][4], fb[2][2];
+        bf16x8_t fa[2][NF], fb[2][2];
         // R(t, jj) of sub-step h: A from slot h & 3, B from the halo buffer of its chunk
         auto reads = [&](auto tc, auto jc, int h, unsigned boff) {
             constexpr int t = decltype(tc)::value, jj = decltype(jc)::value;
             const unsigned aa = a_lane + (unsigned)((h & 3) * L::STAGE);
             lds_read16_asm<0 * 2048 + jj * 1024>(fa[jj][0], aa);
             lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aa);
-            lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aa);
-            lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aa);
+            if constexpr (NF == 4) {
+                lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aa);
+                lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aa);
+            }
             const unsigned b0 = (bx[t] + boff) ^ (jj << 5);
             lds_read16_asm<0>(fb[jj][0], b0);
             lds_read16_asm<2048>(fb[jj][1], b0);
@@ -656,6 +667,13 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
                     constexpr int jj = decltype(jc)::value;
                     const unsigned b0 = (bx[tn] + boffn) ^ (jj << 5);
 #define SK_MF(f, n) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[jj][f], fb[jj][n], acc[f][n], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                    if constexpr (NF == 2) {
+                        // four MFMAs; every fragment register re-requested right behind the last MFMA that reads it
+                        SK_MF(0, 0); shadow(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
+                        SK_MF(1, 0); lds_read16_asm<0>(fb[jj][0], b0); shadow(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
+                        SK_MF(0, 1); lds_read16_asm<0 * 2048 + jj * 1024>(fa[jj][0], aan); shadow(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+                        SK_MF(1, 1); lds_read16_asm<1 * 2048 + jj * 1024>(fa[jj][1], aan); lds_read16_asm<2048>(fb[jj][1], b0); __builtin_amdgcn_sched_barrier(0);
+                    } else {
                     SK_MF(0, 0); shadow(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(1, 0); shadow(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(2, 0); shadow(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
@@ -668,23 +686,24 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
                     SK_MF(2, 1); lds_read16_asm<2 * 2048 + jj * 1024>(fa[jj][2], aan); __builtin_amdgcn_sched_barrier(0);
                     SK_MF(3, 1); lds_read16_asm<3 * 2048 + jj * 1024>(fa[jj][3], aan); lds_read16_asm<2048>(fb[jj][1], b0); __builtin_amdgcn_sched_barrier(0);
 #endif
+                    }
 #undef SK_MF
                 };
                 // ---- unit (t, 0) ----
 #ifndef SK_ABL_NOREAD
-                lgkm_wait_asm<6>();                                  // R(t, 0) landed (R(t, 1) may be in flight)
+                lgkm_wait_asm<NF + 2>();                             // R(t, 0) landed (R(t, 1) may be in flight)
 #endif
                 unit(std::integral_constant<int, 0>{}, [&](auto) {});
                 // ---- unit (t, 1) ----
 #ifndef SK_ABL_NOREAD
-                lgkm_wait_asm<6>();                                  // R(t, 1) landed: every read of stage h is complete
+                lgkm_wait_asm<NF + 2>();                             // R(t, 1) landed: every read of stage h is complete
 #endif
                 {
                     // S point: stage h + 2 must be in LDS (requested two sub-steps ago); allowed in flight: the halo pieces of S(t - 1) and stage h + 3
                     constexpr int j0p = tm1 * HPER < NHW ? tm1 * HPER : NHW, j1p = (tm1 + 1) * HPER < NHW ? (tm1 + 1) * HPER : NHW;
                     constexpr int c1 = tm1 < TA ? j1p - j0p : 0;      // halo pieces S(t - 1) issued
 #ifndef SK_ABL_NODMA
-                    sk_wait_vm<L::PW + c1>();
+                    sk_wait_vm<PWN + c1>();
 #endif
 #ifndef SK_ABL_NOBAR
                     asm volatile("s_barrier" ::: "memory");
@@ -697,7 +716,7 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
                     constexpr int j0 = t < TA ? (t * HPER < NHW ? t * HPER : NHW) : 0, j1 = t < TA ? ((t + 1) * HPER < NHW ? (t + 1) * HPER : NHW) : 0;
                     constexpr int nh = j1 - j0;                       // halo pieces of this S point; then PW stage pieces
                     // piece list: [halo j0 .. j1) [stage 0 .. PW): piece index q goes to shadow min(q * 3 / total, 2)
-                    constexpr int total = nh + L::PW;
+                    constexpr int total = nh + PWN;
                     static_for<0, total>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
 #ifdef SK_ABL_NODMA
@@ -708,11 +727,11 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
                         if constexpr (sh == sidx) {
                             if constexpr (q < nh) {
                                 constexpr int j = j0 + q;
-                                if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt, j * NW + wave, bnext ? 1 : 0);
+                                if (want_tab && c + 1 == ce && j * NW + wave < NTP) issue_table(cur.rt / RSUB, j * NW + wave, bnext ? 1 : 0);
                                 else issue_halo(j, bnext ? 1 : 0);
                             } else {
                                 constexpr int j = q - nh;
-                                sk_dma16(a_seg + (long long)(cb * NTAPS + h + 4) * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + (h & 3) * L::STAGE + (wave * L::PW + j) * 1024));
+                                sk_dma16(a_seg + (long long)(cb * NTAPS + h + 4) * L::STAGE + j * 1024, lane16, (unsigned)(L::OFF_W + (h & 3) * L::STAGE + (wave * PWN + j) * 1024));
                             }
                         }
                     });
@@ -727,7 +746,7 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(fa[jj][f]));
+            for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(fa[jj][f]));
             asm volatile("" : "+v"(fb[jj][0]), "+v"(fb[jj][1]));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -740,9 +759,10 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
         if (same_rt) prefetch(nxt);
         __builtin_amdgcn_sched_barrier(0);
 
-        if (cb == 0 && ce == nch) {
-            sk_epilogue<MW, NW, L::LDS_TAB ? 1 : 2, true>(p, smem, nullptr, acc, cur.par, cur.rt, qbase + cur.tile * L::NPX, wm, wn, lane, tab_base);
-        } else {
+        if (NF != 4 || (cb == 0 && ce == nch)) {                      // (short units are never cut)
+            sk_epilogue<MW, NW, L::LDS_TAB ? 1 : 2, true, NF>(p, smem, nullptr, acc, cur.par, cur.rt / RSUB, qbase + cur.tile * L::NPX, wm, wn, lane, tab_base, -1,
+                                                             (cur.rt % RSUB) * (32 * NF));
+        } else if constexpr (NF == 4) {
             // raw accumulators, accumulator layout: [wave][f][n][reg / 4][lane][4] fp32 - coalesced 16-byte stores
             float* pw = p.partial + ((long long)(2 * lid + (cur.first_sk ? 0 : 1))) * L::part_floats() + wave * (128 * 64) + lane * 4;
 #pragma unroll
@@ -770,6 +790,16 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
 #endif
 }
 
+// WIDE and SHORT units in one launch (round 6: the 36^2 level at B = 16; p.mix_nunits > 0, the <1, 4, 9> instantiation only).  344 units of 128 rows x
+// 256 positions on 512 resident slots leave 168 CUs with ONE workgroup and give 88 two; a workgroup puts one wave on every SIMD and the matrix pipe
+// belongs to the SIMD, so the launch lasts as long as two 128 x 64 wave tiles on one SIMD (a unit takes ~96 us alone, ~180 us beside a second one).
+// In a mixed launch the first mix_wt pixel tiles are computed as wide units, the remaining mix_nt as SHORT units (conv_sk_body<.., NF = 2>: 64 rows,
+// wave tile 64 x 64 - half the work per wave, same halo) such that wide + short units = 2 x CUs: every CU gets exactly two workgroups and no SIMD
+// more than a wide and a short wave tile.  (A first version halved the POSITIONS instead - 128 x 128 units of two waves - and changed nothing: that
+// halves the waves, not a wave's work; profiles/EXPERIMENTS.md.)  Order: XCD x gets the x-th eighth of the wide units, then the x-th eighth of the
+// short ones (both counts multiples of 8); within an XCD workgroups are handed out in blockIdx order and every CU takes one before any takes a
+// second, in the same CU order (tools/micro/dispatch_map.hip: (j, j + 32) on one CU for 512 / 512 pairs), so the wide ones, dispatched first, land
+// on different CUs and each gets a short partner.  The block's res_conv units stay wide and stay the grid's tail.
 template <int MW, int NW, int NTAPS>
 __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -781,9 +811,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
             const int nmain = nblk - p.alt_units;
             if (bid >= nmain) { alt = true; bid -= nmain; nblk = p.alt_units; } else nblk = nmain;
         }
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        G = nblk;
+        bool mixed = false;
+        if constexpr (MW == 1 && NW == 4 && NTAPS == 9) {
+            if (p.mix_nunits && !alt) {
+                // (G, the unit count and the whole-unit count reach the body as separate run-time values although a mixed launch has them equal:
+                // with `ndp == units == G` visible at compile time hipcc folds the segment loop away and the code that is left spills 56 - 125 registers)
+                mixed = true;
+                const int wu = p.units, nu = p.mix_nunits;           // wide / short units (multiples of 8)
+                const int xcd = bid & 7, j = bid >> 3, wpx = wu >> 3, npx = nu >> 3;
+                if (j < wpx) { lid = xcd * wpx + j; G = wu; }
+                else { conv_sk_body<1, 4, 9, 2>(p, smem, xcd * npx + (j - wpx), nu, nu, p.mix_nndp, p.mix_q0, p.nhp); return; }
+            }
+        }
+        if (!mixed) {
+            const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+            lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+            G = nblk;
+        }
         if (MW == 1 && NW == 4) {
             if (alt) {
                 const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -793,42 +837,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_sk_kernel(const ConvSkP p) {
         }
     }
     conv_sk_body<MW, NW, NTAPS>(p, smem, lid, G, p.units, p.ndp, 0, p.nhp);
-}
-
-// WIDE and NARROW units in one launch (round 6: the 36^2 level at B = 16).  364 units of 128 rows x 256 positions on 512 resident slots leave 148
-// CUs with ONE workgroup (a unit takes ~96 us alone and ~180 us beside a second one: the launch takes the 180).  Here the position space is cut
-// into mix_wt WIDE tiles of 256 positions (four waves) followed by mix_nt NARROW tiles of 128 positions (the same 128 x 64 wave tile and K loop
-// in TWO waves; waves 2 - 3 of the workgroup exit at once) such that (mix_wt + mix_nt) * rowtiles = 2 x CUs: every CU gets exactly two
-// workgroups, a wide and a narrow one or two narrow ones - 1.5 instead of 2 units of work on the busiest CU.  Order: XCD x gets the x-th eighth
-// of the wide units, then the x-th eighth of the narrow ones (both multiples of 8); within an XCD workgroups are handed out in blockIdx order
-// and every CU takes one before any takes a second (tools/micro/dispatch_map.hip), so the wide ones, dispatched first, land on different CUs.
-// The block's res_conv units stay wide and stay the grid's tail.
-template <int NTAPS>
-__global__ __launch_bounds__(256, 2) void conv_sk_mix_kernel(const ConvSkP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nmain = (int)gridDim.x - p.alt_units;
-    int bid = blockIdx.x;
-    if (bid >= nmain) {                                              // res_conv tail, as in conv_sk_kernel
-        bid -= nmain;
-        const int nblk = p.alt_units, q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        sk_alt_unit<4>(p, smem, lid, wave, lane);
-        return;
-    }
-    // (units and whole-unit counts come from separate fields of p although the host sets them equal: with `ndp == units == G` visible at compile
-    // time hipcc folds the segment loop away and the code that is left spills 56 - 125 registers; this way the bodies compile as in conv_sk_kernel)
-    const int wu = p.units, nu = p.mix_nunits;                       // wide / narrow units (multiples of 8)
-    const int xcd = bid & 7, j = bid >> 3, wpx = wu >> 3, npx = nu >> 3;
-#ifdef SK_MIX_ONLY_NARROW
-    if (j < wpx) return;
-#else
-    if (j < wpx) { conv_sk_body<1, 4, NTAPS>(p, smem, xcd * wpx + j, wu, wu, p.ndp, 0, p.nhp); return; }
-#endif
-#ifndef SK_MIX_ONLY_WIDE
-    if (threadIdx.x >= 128) return;                                  // (s_barrier counts the workgroup's live waves only)
-    conv_sk_body<1, 2, NTAPS>(p, smem, xcd * npx + (j - wpx), nu, nu, p.mix_nndp, p.mix_q0, p.mix_nhp);
-#endif
 }
 
 // Second half of a stream-K launch: sums the partial tiles of every cut unit in ascending workgroup order (fixed: bit-reproducible)

@@ -236,7 +236,7 @@ static void ensure_kernel_attrs() {
     set_lds_attr(conv_sk_kernel<2, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<2, 8, 4>, 160 * 1024);
     set_lds_attr(conv_sk_kernel<1, 8, 9>, 160 * 1024); set_lds_attr(conv_sk_kernel<1, 8, 4>, 160 * 1024);
     set_lds_attr(conv_sk_kernel<1, 4, 9>, 80 * 1024, true); set_lds_attr(conv_sk_kernel<1, 4, 4>, 80 * 1024, true);
-    set_lds_attr(conv_sk_mix_kernel<9>, 80 * 1024, true);
+
     set_lds_attr(final_conv_kernel, 160 * 1024);
     set_lds_attr(flash_attn_kernel<1, false>, fa_lds_bytes(128)); set_lds_attr(flash_attn_kernel<1, true>, fa_lds_bytes(128));
     set_lds_attr(flash_attn_kernel<2, false>, fa_lds_bytes(256)); set_lds_attr(flash_attn_kernel<2, true>, fa_lds_bytes(256));
@@ -461,7 +461,7 @@ static int choose_usplit(int nblk) {
 
 // ---- conv_sk_kernel (conv_sk.hip.h): persistent stream-K 3x3 conv / Upsample parity classes on 256-row tiles -------------------------
 static std::atomic<int> g_convsk{-1};          // -1: environment (UCDIR_NO_CONV_SK) + work threshold, 0: off, 1: forced (tests: any size)
-static std::atomic<int> g_skmix{-1};           // conv_sk_mix_kernel: -1 environment (UCDIR_SK_MIX=0 off) + its occupancy rule, 0 off, 1 forced at any size (tests)
+static std::atomic<int> g_skmix{-1};           // conv_sk_kernel<1, 4, 9> with wide + short units: -1 environment (UCDIR_SK_MIX=0 off) + its occupancy rule, 0 off, 1 forced at any size (tests)
 template <int MW, int NW>
 static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y, bool upph, int act, const Act* res, bool want_stats, hipStream_t st, int mode, bool* did_res, Act* res_out, const ConvW* wres) {
     using L = CvSk<MW, NW>;
@@ -539,35 +539,39 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
         const long long rem = (long long)p.units - p.ndp;
         if (rem > 0 && rem * p.nchunks < G && p.ndp >= G) p.ndp -= G;
     }
-    // wide + narrow units in one launch (conv_sk_mix_kernel): between one and two workgroups per CU - the 36^2 level at B = 16, 364 (shared
-    // borders: 344) units on 512 resident slots - every CU gets exactly two workgroups: wt tiles of 256 positions, then nt tiles of 128
-    // positions, (wt + nt) * rowtiles = 2 x CUs, both unit counts multiples of 8 (an eighth per XCD)
+    // wide + SHORT units in one launch (conv_sk_kernel<1, 4, 9>, p.mix_nunits > 0): between one and two workgroups per CU - the 36^2 level at B = 16, 344 units on 512
+    // resident slots.  The matrix pipe belongs to the SIMD, a workgroup puts one wave on each: a CU with two wide workgroups has two 128 x 64 wave
+    // tiles per SIMD, one with a single workgroup one - the launch lasts as long as the former.  The last nt pixel tiles are computed as SHORT
+    // units (64 rows x 256 positions, 64 x 64 wave tiles: half a wide unit) so that wide + short units = 2 x CUs: every CU holds two workgroups
+    // and no SIMD more than 1.5 wide wave tiles.  Both unit counts multiples of 8 (an eighth per XCD; wide ones first in every XCD's order).
     bool mix = false;
     if (NW == 4 && MW == 1 && !upph && !ksplit_on && g_persist_grid <= 0 && G == p.units && p.ndp == p.units) {
         static const bool mix_env = !(getenv("UCDIR_SK_MIX") && atoi(getenv("UCDIR_SK_MIX")) == 0);
         const int force = g_skmix.load();
         const int slots = 2 * num_cus();
         int g8 = 8; while (p.rowtiles % g8) g8 >>= 1;                // gcd(8, rowtiles)
-        const int step = 8 / g8;                                     // tile counts in multiples of `step` make unit counts multiples of 8
-        const int nhp2 = (CvSk<1, 2>::NPX + 2 * Wpe + 2 + 15) / 16;
+        const int step_w = 8 / g8;                                   // wide tiles in multiples of step_w: wide units a multiple of 8
+        int g8s = 8; while ((2 * p.rowtiles) % g8s) g8s >>= 1;
+        const int step_s = 8 / g8s;                                  // short tiles likewise (2 x rowtiles units each)
         int wt = 0, nt = 0;
-        if (force > 0) {                                              // tests: both kinds at any size
-            wt = step;
-            const long long rest = npos - 256LL * wt;
-            nt = rest > 0 ? (int)((rest + 127) / 128) : 1;
-            nt = (nt + step - 1) / step * step;
-        } else if (force < 0 && mix_env && p.units > num_cus() && p.units < slots && slots % p.rowtiles == 0 && (slots / p.rowtiles) % step == 0) {
-            const int T = slots / p.rowtiles;
-            const long long need = npos - 128LL * T;                  // 256 wt + 128 (T - wt) >= npos
-            wt = need > 0 ? (int)((need + 127) / 128) : 0;
-            wt = (wt + step - 1) / step * step;
-            nt = T - wt;
+        if (force > 0) {                                              // tests: both kinds at any size (tiles past the end of the space are computed and dropped)
+            wt = step_w;
+            nt = p.ntiles - wt; if (nt < 1) nt = 1;
+            nt = (nt + step_s - 1) / step_s * step_s;
+        } else if (force < 0 && mix_env && p.units > num_cus() && p.units < slots) {
+            nt = slots / p.rowtiles - p.ntiles;                       // rowtiles (wt + 2 nt) <= slots with wt + nt = ntiles
+            if (nt > p.ntiles) nt = p.ntiles;
+            nt = nt / step_s * step_s;
+            wt = p.ntiles - nt;
+            while (nt > 0 && wt % step_w) { nt -= step_s; wt += step_s; }
+            if (wt % step_w) nt = 0;
         }
-        if (wt > 0 && nt > 0 && nhp2 <= CvSk<1, 2>::NHP_MAX && 256LL * wt + 128LL * nt >= npos) {
+        if (wt > 0 && nt > 0) {
             mix = true;
-            p.mix_wt = wt; p.mix_nt = nt; p.mix_nhp = nhp2;
-            p.mix_nunits = nt * p.rowtiles; p.mix_nndp = p.mix_nunits; p.mix_q0 = wt * NPX;
-            G = (wt + nt) * p.rowtiles; p.units = wt * p.rowtiles; p.ndp = p.units;
+            p.mix_wt = wt; p.mix_nt = nt; p.mix_nhp = nhp;
+            p.mix_nunits = nt * 2 * p.rowtiles; p.mix_nndp = p.mix_nunits; p.mix_q0 = wt * NPX;
+            p.units = wt * p.rowtiles; p.ndp = p.units;
+            G = p.units + p.mix_nunits;
         }
     }
     if (did_res) *did_res = false;
@@ -583,7 +587,6 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
     const int nsk = p.units - p.ndp;
     p.partial = nsk > 0 ? splitk_scratch() : nullptr;                // (no cut unit, no partial tiles: the single-operator entry points do not allocate the scratch for nothing)
     auto go = [&]() {
-        if (mix) { hipLaunchKernelGGL((conv_sk_mix_kernel<9>), dim3(G), dim3(256), lds, st, p); return; }
         if (upph) hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 4>), dim3(G), dim3(L::THREADS), lds, st, p);
         else hipLaunchKernelGGL((conv_sk_kernel<MW, NW, 9>), dim3(G), dim3(L::THREADS), lds, st, p);
         if (nsk > 0) hipLaunchKernelGGL((conv_sk_finish_kernel<MW, NW>), dim3(4 * NW, nsk), dim3(64), 0, st, p, Gmain);
@@ -1886,7 +1889,7 @@ int32_t ucdir_debug_flag(const char* name, int32_t value) {
     else if (!strcmp(name, "flash")) g_flash = value;            // attention: 1 flash kernel, 0 materialised scores, -1 environment
     else if (!strcmp(name, "splitk")) g_splitk = value;     // split-K / unit split for under-filled grids: 1 on, 0 off, -1 environment
     else if (!strcmp(name, "wsb")) g_wsb = value;
-    else if (!strcmp(name, "skmix")) g_skmix = value;         // conv_sk_mix_kernel (wide + narrow units): 1 forced at any size, 0 off, -1 environment + occupancy rule
+    else if (!strcmp(name, "skmix")) g_skmix = value;         // conv_sk_kernel<1, 4, 9> with wide + short units: 1 forced at any size, 0 off, -1 environment + occupancy rule
     else if (!strcmp(name, "convsk")) g_convsk = value;       // stream-K conv: 1 forced at any size, 0 off, -1 environment + work threshold
     else if (!strcmp(name, "persist_grid")) g_persist_grid = value;   // persistent kernels: workgroups per launch (0 = one per CU)
     else throw std::runtime_error(std::string("unknown debug flag ") + name);
