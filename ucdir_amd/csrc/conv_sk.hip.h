@@ -67,7 +67,8 @@ struct ConvSkP {
     int alt_units; const bf16_t* alt_A; const float* alt_bias; bf16_t* alt_out; int alt_out_ld;
     // mixed launch (conv_sk_kernel<1, 4, 9>, mix_nunits > 0): units (= ndp) wide units over the first mix_wt pixel tiles, then mix_nunits (= mix_nndp) SHORT units (64 rows: two per
     // 128-row tile) over the mix_nt pixel tiles from position mix_q0 = 256 mix_wt on
-    int mix_wt, mix_nt, mix_nhp, mix_nunits, mix_nndp, mix_q0;
+    // (mix_srt: short units per pixel tile = 2 x rowtiles)
+    int mix_wt, mix_nt, mix_nhp, mix_nunits, mix_nndp, mix_q0, mix_srt;
     unsigned long long* dbg;
 };
 
@@ -517,7 +518,7 @@ __device__ __forceinline__ void conv_sk_body(const ConvSkP& p, unsigned char* sm
             cpos = e;
         } else { s.ok = false; s.unit = 0; s.cb = 0; s.ce = 0; }
         int u = s.unit;
-        const int RT = p.rowtiles * RSUB;                             // units per pixel tile
+        const int RT = NF == 4 ? p.rowtiles : p.mix_srt;              // units per pixel tile (short: two per 128-row tile)
         const int per_par = RT * p.ntiles;
         s.par = 0;
         if (p.npar > 1) { s.par = u / per_par; u -= s.par * per_par; }

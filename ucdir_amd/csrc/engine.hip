@@ -566,10 +566,11 @@ static bool try_conv_sk_mw(const ConvW& w, const Act& x0, const Act* x1, Act& y,
             while (nt > 0 && wt % step_w) { nt -= step_s; wt += step_s; }
             if (wt % step_w) nt = 0;
         }
+        const int srt = 2 * p.rowtiles;                               // short units per pixel tile
         if (wt > 0 && nt > 0) {
             mix = true;
-            p.mix_wt = wt; p.mix_nt = nt; p.mix_nhp = nhp;
-            p.mix_nunits = nt * 2 * p.rowtiles; p.mix_nndp = p.mix_nunits; p.mix_q0 = wt * NPX;
+            p.mix_wt = wt; p.mix_nt = nt; p.mix_nhp = nhp; p.mix_srt = srt;
+            p.mix_nunits = nt * srt; p.mix_nndp = p.mix_nunits; p.mix_q0 = wt * NPX;
             p.units = wt * p.rowtiles; p.ndp = p.units;
             G = p.units + p.mix_nunits;
         }
