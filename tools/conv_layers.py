@@ -54,7 +54,7 @@ for (H, c0, c1, cout, mode) in SHAPES:
                                        C._p(None), C._p(y), C._hp(None), C._st()))
             ulib.check(L.ucdir_profile_enable(0))
             if r:
-                rows = [x for x in prof_read() if x[0] in (20, 21, 22, 120, 121, 125, 126, 127, 128)]
+                rows = [x for x in prof_read() if x[0] in (20, 21, 22, 120, 121, 125, 126, 127, 128, 129)]
                 t = sum(x[2] for x in rows)
                 best = t if best is None or t < best else best
                 key = rows[0][0] if rows else -1

@@ -30,6 +30,7 @@ struct AkgmHP {
     // own_tc (the persistent kernels): no akgm_tc_kernel launch in front - a workgroup entering sample b sums the statistics slots itself and
     // forms its slice of Tc from the sample-independent tables Tbb = bias + Tb and Tg ([9][8C] each) on the way into LDS (akgm_tc_piece)
     int own_tc; const float* Tbb; const float* Tgt;
+    int reverse;                               // persistent kernels: walk the tile range from its end (meets the lines the producer wrote LAST - still in L2 / the Infinity Cache - first)
     unsigned long long* dbg;
 };
 

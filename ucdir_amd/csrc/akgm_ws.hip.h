@@ -159,8 +159,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
 
     int b, ty, tx;                                 // tile t
     {
-        b = t_beg / tps;
-        const int r = t_beg - b * tps;
+        const int t_first = p.reverse ? t_end - 1 : t_beg;
+        b = t_first / tps;
+        const int r = t_first - b * tps;
         ty = r / p.tiles_x; tx = r - ty * p.tiles_x;
     }
     // DMA piece i of a tile (i < 7: this wave's halo piece 8 i + wave; 7: its guide piece) into buffer `buf`
@@ -255,8 +256,9 @@ __global__ __launch_bounds__(HC_THREADS, 2) void akgm_ws_kernel(const AkgmHP p) 
         // (do_pair).  History: plain asm loads with counted waits that took younger DMA pieces for "still in flight" broke
         // bit-reproducibility of a B = 32, T = 100 restoration - an LDS-DMA can retire before an older plain load; plain
         // loads with vmcnt(0) drained the queue every pair.
-        int nb = b, nty = ty, ntx = tx + 1;                          // tile t + 1
-        if (ntx == p.tiles_x) { ntx = 0; if (++nty == p.tiles_y) { nty = 0; ++nb; } }
+        int nb = b, nty = ty, ntx = tx + 1;                          // tile t + 1 (reverse: the tile in front of this one)
+        if (!p.reverse) { if (ntx == p.tiles_x) { ntx = 0; if (++nty == p.tiles_y) { nty = 0; ++nb; } } }
+        else { ntx = tx - 1; if (ntx < 0) { ntx = p.tiles_x - 1; if (--nty < 0) { nty = p.tiles_y - 1; --nb; } } }
         const bf16_t* hbn = halo_base(nb, nty, ntx);
         const float* gbn = guide_base(nb, nty, ntx);
         const unsigned char* resn = res_base(nb, nty, ntx);
