@@ -95,6 +95,7 @@ def main(argv=None):
     # restored in.  --seed fixes the base; without it one draw from torch's CPU generator per run (torch.manual_seed makes it reproducible).
     diffusion.image_seed_base = args.seed if args.seed is not None else int(torch.randint(0, 2 ** 31, (1,)).item())
     t_restore, n_restored = 0.0, 0
+    group_times = []                                              # (images, seconds) of every DDPM.test call (the first one packs the weights)
 
     def restore(group):
         """One DDPM.test call for a group of images of identical (H, W): a batch is B independent restorations (model/diffusion.py:185-211
@@ -113,6 +114,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         t_restore += time.perf_counter() - t0
         n_restored += len(group)
+        group_times.append((len(group), time.perf_counter() - t0))
         if group[0][2] and rank != 0:
             return                                                # sharded image: every rank holds the same result; rank 0 reports it
         name = opt["name"]
@@ -153,6 +155,7 @@ def main(argv=None):
     if n_restored:
         logger.info("restored %d images in %.2f s on this rank (%.2f img/s, batches of up to %d)" % (n_restored, t_restore, n_restored / t_restore, args.batch))
     main.last_throughput = (n_restored, t_restore)
+    main.last_groups = group_times
     acc = torch.tensor([tot_psnr, tot_ssim, float(n)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(acc)
