@@ -18,6 +18,12 @@ template <int OFF>
 __device__ __forceinline__ void lds_read16f_asm(f32x4_t& v, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
+// one LDS-DMA piece (16 bytes per lane, 1 KB per wave) with a wave-uniform SGPR base and a 32-bit per-lane byte offset: no 64-bit per-lane pointer to form or
+// keep (the builtin only takes the VGPR-address form); M0 = the LDS destination, written - and declared clobbered - inside the statement.  hipcc does not count
+// it: the kernels that use it count their vmcnt by hand, and a hidden VMEM operation only makes the compiler's own waits more conservative.
+__device__ __forceinline__ void dma16_sbase(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
 template <int N>
 __device__ __forceinline__ void lgkm_wait_asm() {
     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");

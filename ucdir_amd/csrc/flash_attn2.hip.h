@@ -20,6 +20,12 @@ __device__ __forceinline__ void fa2_read16(V& v, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
+// one LDS-DMA piece with a wave-uniform (SGPR) base and a 32-bit per-lane byte offset (conv_sk.hip.h's form: no 64-bit per-lane pointer - the pieces are
+// issued between the MFMAs now, where two more live registers per piece spilled at C = 512); M0 = the LDS destination, written inside the statement
+__device__ __forceinline__ void fa2_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
 // C = 128 * NC channels (NC = 1 .. 4); the head is the whole channel dimension
 template <int NC, bool HALF>
 __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP p) {
@@ -55,33 +61,42 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP
     const unsigned char* kglob = reinterpret_cast<const unsigned char*>(qkvb + C);
     const unsigned char* vglob = reinterpret_cast<const unsigned char*>(vtb);
     const unsigned krow_bytes = (unsigned)p.ld * 2, vrow_bytes = (unsigned)p.Npad * 2;
-    auto issue_K = [&](int t) {
+    // (round 6: one piece per call - the pieces of K(t + 1) and V't(t) are issued BETWEEN the MFMAs of the PV / S phase instead of as a block of
+    // 2 NC instructions per wave at the phase's head.  s_memtime stamps: with every fragment read removed the PV phase still took 4.6 k cycles for 2 k of
+    // matrix work - all eight waves issued their eight LDS-DMAs (~100 - 185 cycles each inside such a phase) at the same time and the matrix pipe sat
+    // idle meanwhile; spread out, one wave's DMA issue runs under its SIMD partner's MFMAs.)
+    constexpr int NPIECE = 2 * NC;                     // DMA instructions per wave for a K tile, and for a V't tile (C / 64)
+    auto issue_K_piece = [&](int t, int i) {
         constexpr int LPR = KROW / 16;                 // lanes per key row (64 | 48 | 32 | 16)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int i = 0; i < (FA_BK * LPR / 64) / 8; ++i) {
-            const int inst = i * 8 + wave;
-            const int e = inst * 64 + ln, r = e / LPR, j = e - r * LPR;      // LPR = 64: r = inst (uniform), j = lane
+        const int inst = i * 8 + wave;
+        if constexpr (LPR == 64) {                     // C = 512: one key row per instruction - the row is wave-uniform and goes into the SGPR base
+            int kg = t * FA_BK + inst; kg = kg < N ? kg : N - 1;
+            const unsigned char* rowp = kglob + (size_t)__builtin_amdgcn_readfirstlane(kg) * krow_bytes;
+            fa2_dma16(rowp, (unsigned)((ln ^ (inst & 15)) << 4), (unsigned)__builtin_amdgcn_readfirstlane(inst * 1024));
+        } else {
+            const int e = inst * 64 + ln, r = e / LPR, j = e - r * LPR;
             int kg = t * FA_BK + r; kg = kg < N ? kg : N - 1;
             const unsigned off = (unsigned)kg * krow_bytes + (unsigned)((j ^ (r & 15)) << 4);
-            stage16(reinterpret_cast<const bf16_t*>(kglob + off), Kl + inst * 1024, lane);
+            fa2_dma16(kglob, off, (unsigned)__builtin_amdgcn_readfirstlane(inst * 1024));                     // (the K tile sits at LDS offset 0)
         }
+    };
+    auto issue_K = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) issue_K_piece(t, i);
     };
     // V't tile: rows = channels, 64 keys (128 bytes) per row; one instruction = 8 rows; chunk ^= (row >> 1) & 7.
     // (row >> 1) & 7 = 4 (inst & 1) | (lane >> 4) and inst & 1 = wave & 1 for all of a wave's instructions: the per-lane
     // offset is the same for all of them
-    auto issue_V = [&](int t) {
+    auto issue_V_piece = [&](int t, int i) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const unsigned lc = (unsigned)((ln & 7) ^ (ln >> 4) ^ ((wave & 1) << 2));
         const unsigned off = (unsigned)(ln >> 3) * vrow_bytes + lc * 16;
-#pragma unroll
-        for (int i = 0; i < C / 8 / 8; ++i) {
-            const int inst = i * 8 + wave;
-            const unsigned char* rowp = vglob + (size_t)(inst * 8) * vrow_bytes + (size_t)t * (FA_BK * 2);     // wave-uniform
-            stage16(reinterpret_cast<const bf16_t*>(rowp + off), Vl + inst * 1024, lane);
-        }
+        const int inst = i * 8 + wave;
+        const unsigned char* rowp = vglob + (size_t)(inst * 8) * vrow_bytes + (size_t)t * (FA_BK * 2);         // wave-uniform
+        fa2_dma16(rowp, off, (unsigned)__builtin_amdgcn_readfirstlane(FA_BK * KROW + inst * 1024));
     };
 
 #ifdef UCDIR_TIMING
@@ -131,10 +146,9 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP
         FA_STAMP();                                                 // [6k+2] K wait done
         __syncthreads();                                            // ... for every wave; PV(t-1) done: P, V't free
         FA_STAMP();                                                 // [6k+3] barrier A passed
-#ifdef FA_ABL_NODMA
-        if (t == 0)
+#ifdef FA2_BLOCK_V
+        for (int i = 0; i < NPIECE; ++i) issue_V_piece(t, i);
 #endif
-        issue_V(t);
         // ---- S^T = K Q^T --------------------------------------------------------------------------------------
         f32x4_t sacc[4];
 #pragma unroll
@@ -163,6 +177,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP
                 sacc[kt] = fa_mfma16(kf[kt], qf[ks], sacc[kt]);
                 if constexpr (ks + 1 < NKS) fa2_read16<((ks + 1) >> 2) * 256 + kt * 16 * KROW>(kf[kt], ka((ks + 1) & 3));
             });
+#ifndef FA2_BLOCK_V
+            // (measured against this placement, same box, N = 1296 / B = 16: every second step over the whole phase 100.5 us, two pieces per step over
+            // the first quarter 100.0, this 95.6, the block at the phase's head 103.0)
+            if constexpr (ks < NPIECE) issue_V_piece(t, ks);        // V't(t): one piece behind each of the first 2 NC k steps (of 4 NC)
+#endif
         });
         __builtin_amdgcn_s_setprio(0);
 #ifdef UCDIR_TIMING
@@ -205,8 +224,10 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // V't(t) landed
         __syncthreads();                                            // P, alpha visible; every wave done with K(t)
         FA_STAMP();                                                 // [6k+6] V wait + barrier B passed
-#ifndef FA_ABL_NODMA
-        if (t + 1 < ntiles) issue_K(t + 1);
+        const bool more = t + 1 < ntiles;
+        const int tnext = more ? t + 1 : t;
+#ifdef FA2_BLOCK_K
+        if (more) issue_K(t + 1);
 #endif
         // ---- O^T = alpha O^T + V't P^T ----------------------------------------------------------------------------
         // the rescale decision first (its two LDS reads are the compiler's own: waited for before the uncounted fragment reads go out)
@@ -236,22 +257,38 @@ __global__ __launch_bounds__(FA_THREADS, 2) void flash_attn2_kernel(const FlashP
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { oacc[dt][0][e] *= a0; oacc[dt][1][e] *= a1; }
         }
+#ifndef FA2_ABL_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         static_for<0, 4>([&](auto kc) {
             constexpr int k16 = decltype(kc)::value;
+#ifndef FA2_ABL_PVNOREAD
             if constexpr (k16 + 1 < 4) pfrag(std::integral_constant<int, k16 + 1>{}, pf[(k16 + 1) & 1]);
+#endif
             static_for<0, NC>([&](auto dc) {
                 constexpr int dt = decltype(dc)::value;
                 // younger than V't(k16, dt): the rest of this step's V't, the next step's two P, the next step's V't requested so far
+#ifndef FA2_ABL_PVNOREAD
                 lgkm_wait_asm<(k16 + 1 < 4) ? NC + 1 : NC - 1 - dt>();
+#else
+                if constexpr (k16 == 0 && dt == 0) lgkm_wait_asm<0>();
+#endif
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = fa_mfma32(vf[dt], pf[k16 & 1][qt], oacc[dt][qt]);
+#ifndef FA2_ABL_PVNOREAD
                 if constexpr (k16 + 1 < 4) fa2_read16<32 * dt * 128>(vf[dt], va ^ (unsigned)(32 * (k16 + 1)));
+#endif
+#ifndef FA2_BLOCK_K
+                // K(t + 1): behind the first 2 NC of the 4 NC MFMA pairs (behind the last tile: that tile again, into the dead K buffer - no branch
+                // around the pieces: with one hipcc kept all eight offsets live across the loop and spilled them)
+                if constexpr (k16 * NC + dt < NPIECE) issue_K_piece(tnext, k16 * NC + dt);
+#endif
             });
         });
         __builtin_amdgcn_s_setprio(0);
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the pieces issued behind the last tile)
 #ifdef UCDIR_TIMING
     asm volatile("" :: "v"(oacc[0][0][0]), "v"(oacc[NC - 1][1][15]));
     FA_STAMP();
